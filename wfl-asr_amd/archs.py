@@ -1,0 +1,109 @@
+"""Built-in encoder dimension table.
+
+The reference gets these by fetching the HuggingFace config *by model name* every time a
+model is built (/root/reference/model.py:69-70, 74-80).  Head count and mel-bin count are not
+recoverable from a checkpoint (q_proj is [d, d] for any head count; the feature extractor is
+not an nn.Module), so the build keeps the public values here, keyed by the same names the
+reference's config.yaml uses (`model.whisper_model` / `model.wavlm_model`).  A config may
+override any field through `model.encoder_arch: {...}`.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+
+
+@dataclass
+class WhisperArch:
+    d_model: int
+    layers: int
+    heads: int
+    ffn: int
+    n_mels: int = 80
+    max_positions: int = 1500   # encoder output frames; mel frames = 2 * max_positions
+    n_fft: int = 400
+    hop: int = 160
+
+
+@dataclass
+class WavLMArch:
+    d_model: int
+    layers: int
+    heads: int
+    ffn: int
+    conv_dim: tuple = (512,) * 7
+    conv_kernel: tuple = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: tuple = (5, 2, 2, 2, 2, 2, 2)
+    feat_extract_norm: str = "group"      # "group" (base) | "layer" (large)
+    conv_bias: bool = False
+    stable_layer_norm: bool = False        # large: True
+    pos_conv_kernel: int = 128
+    pos_conv_groups: int = 16
+    num_buckets: int = 320
+    max_distance: int = 800
+    do_normalize: bool = False             # from the hub preprocessor_config.json (base: False, large: True)
+    layer_norm_eps: float = 1e-5
+
+
+WHISPER = {
+    "tiny": WhisperArch(384, 4, 6, 1536),
+    "base": WhisperArch(512, 6, 8, 2048),
+    "small": WhisperArch(768, 12, 12, 3072),
+    "medium": WhisperArch(1024, 24, 16, 4096),
+    "large": WhisperArch(1280, 32, 20, 5120),
+    "large-v2": WhisperArch(1280, 32, 20, 5120),
+    "large-v3": WhisperArch(1280, 32, 20, 5120, n_mels=128),
+    "large-v3-turbo": WhisperArch(1280, 32, 20, 5120, n_mels=128),
+}
+
+WAVLM = {
+    "base": WavLMArch(768, 12, 12, 3072),
+    "base-plus": WavLMArch(768, 12, 12, 3072),
+    "base-sv": WavLMArch(768, 12, 12, 3072),
+    "large": WavLMArch(1024, 24, 16, 4096, feat_extract_norm="layer", conv_bias=True,
+                       stable_layer_norm=True, do_normalize=True),
+}
+
+
+def _suffix(name: str, prefix: str) -> str:
+    base = name.rstrip("/").split("/")[-1].lower()
+    if base.endswith(".en"):
+        base = base[:-3]
+    if base.startswith(prefix):
+        base = base[len(prefix):]
+    return base.lstrip("-_")
+
+
+def resolve_encoder_arch(model_cfg: dict):
+    """config["model"] -> ("whisper", WhisperArch) | ("wavlm", WavLMArch).
+
+    Mirrors the selection at /root/reference/model.py:57-81; `encoder_type: none` (torchaudio
+    mel path, model.py:82-91) is out of scope and raises.
+    """
+    enc = str(model_cfg["encoder_type"]).lower()
+    override = dict(model_cfg.get("encoder_arch") or {})
+    if enc == "whisper":
+        key = _suffix(str(model_cfg["whisper_model"]), "whisper")
+        table, cls = WHISPER, WhisperArch
+    elif enc == "wavlm":
+        key = _suffix(str(model_cfg["wavlm_model"]), "wavlm")
+        table, cls = WAVLM, WavLMArch
+    elif enc in ("none", "null"):
+        raise ValueError("encoder_type 'none' (torchaudio mel front-end) is outside the accelerated hot path")
+    else:
+        raise ValueError("Unsupported encoder type. Use 'whisper', 'wavlm', or 'none'.")
+    if key in table:
+        arch = dataclasses.replace(table[key])
+    elif override and all(k in override for k in ("d_model", "layers", "heads", "ffn")):
+        arch = cls(override["d_model"], override["layers"], override["heads"], override["ffn"])
+    else:
+        raise ValueError(
+            f"unknown {enc} model '{key}': add model.encoder_arch {{d_model, layers, heads, ffn, ...}} to the config"
+        )
+    for k, v in override.items():
+        if not hasattr(arch, k):
+            raise ValueError(f"model.encoder_arch has no field '{k}'")
+        if isinstance(getattr(arch, k), tuple):
+            v = tuple(v)
+        setattr(arch, k, v)
+    return enc, arch
