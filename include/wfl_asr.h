@@ -1,0 +1,150 @@
+/* wfl_asr.h — C ABI of libwfl_asr_hip.so, the MI355X (gfx950) implementation of the WFL-ASR labeling hot path.
+ *
+ * The reference (usamireko/WFL-ASR) has no plugin / operator / FFI layer: its hot path sits behind plain Python
+ * callables.  This header is therefore the build's own boundary; every entry point names the
+ * reference interface it replaces so a maintainer can bind it from the reference's Python (ctypes stub in
+ * INTEGRATION.md).  Conventions:
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - the caller owns every buffer (PyTorch-ROCm allocations are fine: pass tensor.data_ptr());
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it and nothing here synchronises the device;
+ *   - return value 0 = ok, negative = error (wfl_last_error() gives the text); no exceptions cross the ABI;
+ *   - one model handle per process per GPU; a handle is not re-entrant.
+ */
+#ifndef WFL_ASR_H
+#define WFL_ASR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wfl_model wfl_model;
+
+#define WFL_ENC_WHISPER 0
+#define WFL_ENC_WAVLM 1
+
+#define WFL_ABI_VERSION 1
+
+/* Architecture = what /root/reference/model.py:54-146 reads from config.yaml plus the HF encoder config it
+ * fetches by name (model.py:69-70, 74-80).  All int32, 64 slots, zero-initialise then fill. */
+typedef struct wfl_arch {
+  int32_t abi_version;       /* WFL_ABI_VERSION */
+  int32_t encoder_type;      /* WFL_ENC_* */
+  int32_t d_model;
+  int32_t enc_layers;
+  int32_t enc_heads;
+  int32_t enc_ffn;
+  int32_t n_mels;            /* whisper: 80 | 128 */
+  int32_t max_positions;     /* whisper: encoder frames (1500); mel frames = 2x */
+  /* head (model.py:96-142) */
+  int32_t num_classes;       /* len(phonemes.txt) */
+  int32_t o_id;              /* class index of "O" */
+  int32_t num_languages;
+  int32_t lang_emb_dim;
+  int32_t enable_bilstm;
+  int32_t bilstm_layers;
+  int32_t n_conformer;
+  int32_t conformer_heads;
+  int32_t conformer_ff_expansion;
+  int32_t conformer_kernel;
+  int32_t enable_dilated;
+  int32_t dilated_depth;
+  int32_t dilated_kernel;
+  /* wavlm (HF WavLMConfig) */
+  int32_t wavlm_n_conv;              /* 7 */
+  int32_t wavlm_conv_dim[8];
+  int32_t wavlm_conv_kernel[8];
+  int32_t wavlm_conv_stride[8];
+  int32_t wavlm_group_norm;          /* 1: feat_extract_norm == "group" */
+  int32_t wavlm_conv_bias;
+  int32_t wavlm_stable_layer_norm;
+  int32_t wavlm_pos_conv_kernel;
+  int32_t wavlm_pos_conv_groups;
+  int32_t wavlm_num_buckets;
+  int32_t wavlm_max_distance;
+  int32_t wavlm_do_normalize;
+  int32_t reserved[10];
+} wfl_arch;
+
+const char* wfl_last_error(void);
+int32_t wfl_abi_version(void);
+
+/* Replaces BIOPhonemeTagger.__init__ (model.py:55-146): builds an empty model for `arch`. */
+int32_t wfl_create(const wfl_arch* arch, wfl_model** out);
+void wfl_destroy(wfl_model* m);
+
+/* Replaces nn.Module.load_state_dict(strict=True) as called at /root/reference/infer.py:206-207: call once per
+ * state-dict tensor with the reference's own key names (fp32 host data; `num_batches_tracked` is ignored). */
+int32_t wfl_load_tensor(wfl_model* m, const char* name, const float* data_host, const int64_t* shape, int32_t ndim);
+
+/* Strict key check + weight packing (q/k/v packing and scaling, BatchNorm fold into the k=31 conv, conv weights to
+ * tap-major GEMM form, GLU row interleave, language-bias table, bf16 conversion, upload).  After this the model
+ * is immutable.  Missing or unexpected keys are an error, as with strict loading. */
+int32_t wfl_finalize(wfl_model* m);
+
+/* Output frames for L input samples per clip (Whisper: always max_positions; WavLM: conv arithmetic). */
+int32_t wfl_num_frames(const wfl_model* m, int32_t L);
+int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
+
+/* lang_mode for wfl_forward */
+#define WFL_LANG_NONE 0     /* forward(lang_id=None): skip lang_proj (model.py:176) */
+#define WFL_LANG_IDS 1      /* lang_id[B] given */
+#define WFL_LANG_AVERAGE 2  /* infer.py:146-156 / 266-276: every language id, mean of logits and of offsets
+                               (the encoder runs once; only the head depends on the language) */
+
+/* Replaces BIOPhonemeTagger.forward (model.py:148-194) + decode_predictions (196-198) + the softmax/threshold
+ * half of suppress_low_confidence (infer.py:86-96) for a batch of clips.
+ *   wav        [B][ldw] fp32 16 kHz samples, L valid columns; lens (optional, [B] int32) marks shorter clips
+ *   ids        [B][T] int32  argmax class, or o_id where max prob < threshold
+ *   argmax     [B][T] int32  raw argmax                      (optional)
+ *   maxprob    [B][T] fp32   max softmax probability
+ *   offsets    [B][T][2] fp32 sigmoid sub-frame offsets
+ *   logits     [B][T][C] fp32                                (optional)
+ *   hidden     [B][T][d] fp32 encoder output                 (optional, parity tests)
+ */
+int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,
+                    const int32_t* lang_id, int32_t lang_mode, float threshold, void* workspace,
+                    int64_t workspace_bytes, int32_t* ids, int32_t* argmax, float* maxprob, float* offsets,
+                    float* logits, float* hidden, void* stream);
+
+/* ---- single stages, exported for unit parity tests and profiling ---- */
+
+/* Replaces WhisperFeatureExtractor.__call__ at model.py:153-154 (HF feature_extraction_whisper.py:135-168).
+ * out [B][n_mels][2*max_positions] fp32, the reference's layout. */
+int32_t wfl_logmel(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,
+                   float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* bf16 MFMA GEMM with fused epilogue on frame rows (see csrc/common.h for the row layout):
+ *   C[row(b,t)][n] = res + alpha * act( sum_k A[m][k] W[n][k] + bias[n] )      m = b*P + t, stored iff t < T
+ * A, W, C(bf16 unless out_f32), res are bf16; K % 64 == 0, N % 128 == 0; k is split into taps of `cin` channels
+ * `tap_stride` elements apart (cin >= K: one contiguous run).  glu: W rows interleaved (16 a | 16 gate). */
+int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride, const void* W, int32_t M, int32_t N,
+                    int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead,
+                    int32_t c_pitch, const float* bias, const void* res, int64_t ldres, float alpha, int32_t act,
+                    int32_t glu, int32_t out_f32, void* Vt, int32_t vt_n0, void* stream);
+
+/* softmax(q k^T) v per (clip, head); QK rows hold [q | k] (q pre-scaled by hd^-1/2 * log2 e), Vt = V transposed. */
+int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* Vt, void* O, int64_t ldo, int32_t B,
+                         int32_t T, int32_t P, int32_t heads, int32_t d, void* stream);
+
+int32_t wfl_op_layernorm(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
+                         float eps, int64_t lead, int32_t B, int32_t P, int32_t T, int32_t C, void* stream);
+
+/* softmax max-prob / argmax / threshold over fp32 logits rows (infer.py:86-96). */
+int32_t wfl_op_tag_decide(const float* logits, int64_t ldl, int32_t rows, int32_t C, float threshold, int32_t o_id,
+                          int32_t* ids, int32_t* argmax, float* maxprob, void* stream);
+
+/* Per-kernel timing hook for bench.py's roofline: when enabled, wfl_forward brackets every GEMM launch with
+ * hipEvents on `stream`.  wfl_gemm_profile_read synchronises on them and returns, per GEMM kernel variant
+ * (key = act | glu<<3 | out_f32<<4 | vt<<5, one template instantiation = one rocprof kernel name), the launch
+ * count, summed milliseconds and summed algorithmic FLOPs (2 * valid_rows * n_valid * K) since the last reset. */
+int32_t wfl_gemm_profile_enable(wfl_model* m, int32_t on);
+int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys, int64_t* launches, double* total_ms,
+                              double* total_flops, int32_t* n_variants, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,226 @@
+"""-m gpu: the whole HIP forward (through wfl_forward) against the golden fixtures (outputs of the reference) and
+against the oracle on the same seeded inputs, plus size-independent properties at BASELINE config-2 size.
+
+Tolerances (bf16 weights/activations with fp32 accumulation vs the fp32 reference), stated once here:
+  log-mel (fp32 path)        |err| <= 2e-3 everywhere, mean |err| <= 1e-4         (near-floor bins are fp32-FFT noise)
+  encoder hidden (LN output) |err| <= 0.08 abs (values are O(1)), mean |err| <= 0.012
+  logits (std ~6.5)          |err| <= 0.6 abs, mean |err| <= 0.08
+  max-prob                   |err| <= 0.08;  offsets |err| <= 0.03
+  tag ids                    identical on every frame whose fp32 top-2 logit margin > TAU = 1.0
+                             and whose max-prob is further than 0.08 from the threshold; >= 97 % of frames qualify
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wfl_oracle as O
+from wfl_asr_amd import synth
+from wfl_asr_amd.archs import resolve_encoder_arch
+from wfl_asr_amd.tagger import BIOPhonemeTagger
+from cases import GOLDEN_CASES, tiny_whisper_config
+
+pytestmark = pytest.mark.gpu
+
+TAU = 1.0
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _note(name, **kw):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, "parity_stats.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **{k: (float(v) if hasattr(v, "__float__") else v) for k, v in kw.items()})) + "\n")
+    except OSError:
+        pass
+
+
+def _build(cfg, n_phonemes, seed):
+    labels = synth.make_labels(n_phonemes)
+    sd_np = synth.make_state_dict(cfg, len(labels), seed=seed)
+    m = BIOPhonemeTagger(cfg, labels)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.to("cuda").eval()
+    return m, labels, sd_np
+
+
+def _oracle(cfg, labels, sd_np, wav, lang):
+    enc, arch = resolve_encoder_arch(cfg["model"])
+    sd = O.to_torch_state_dict(sd_np)
+    lg, of, hid = O.forward(torch.from_numpy(wav), None if lang is None else torch.from_numpy(lang), sd, enc, arch,
+                            synth.head_config(cfg["model"]), return_hidden=True)
+    return lg, of, hid
+
+
+def _check_decisions(name, out, ref_logits, ref_offsets, o_id, thr):
+    ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(ref_logits, o_id, thr)
+    lg = out.logits.cpu()
+    err = (lg - ref_logits).abs()
+    mp_err = (out.maxprob.cpu() - maxp_ref).abs()
+    of_err = (out.offsets.cpu() - ref_offsets).abs()
+    safe = (margin > TAU) & ((maxp_ref - thr).abs() > 0.08)
+    arg_bad = int((out.argmax.cpu().long() != arg_ref)[margin > TAU].sum())
+    ids_bad = int((out.ids.cpu().long() != ids_ref)[safe].sum())
+    _note(name, logits_max=err.max(), logits_mean=err.mean(), maxprob_max=mp_err.max(), offsets_max=of_err.max(),
+          safe_frac=safe.float().mean(), argmax_bad=arg_bad, ids_bad=ids_bad,
+          argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()), frames=int(arg_ref.numel()))
+    assert err.max() <= 0.6 and err.mean() <= 0.08, (err.max(), err.mean())
+    assert mp_err.max() <= 0.08 and of_err.max() <= 0.03, (mp_err.max(), of_err.max())
+    assert arg_bad == 0 and ids_bad == 0
+    assert safe.float().mean() >= 0.80
+
+
+def test_logmel_matches_oracle():
+    cfg = synth.baseline_config(1)
+    m, labels, _ = _build(cfg, 70, seed=1)
+    wav = np.zeros((3, 480000), np.float32)
+    wav[0] = synth.make_clip(1000, 480000, seed=1)
+    wav[1, :160000] = synth.make_clip(1001, 160000, seed=1)       # short clip, zero padded
+    wav[2] = 0.0                                                  # silence: every bin at the 1e-10 clamp
+    got = m.log_mel(torch.from_numpy(wav).cuda()).cpu()
+    ref = O.whisper_log_mel(torch.from_numpy(wav), 80, 480000)
+    err = (got - ref).abs()
+    _note("logmel", max=err.max(), mean=err.mean())
+    assert err.max() <= 2e-3 and err.mean() <= 1e-4
+    assert torch.equal(got[2], ref[2])                            # constant -1.5 everywhere
+    # lens: a ragged batch equals explicit zero padding
+    lens = torch.tensor([480000, 160000, 0], dtype=torch.int32)
+    junk = wav.copy(); junk[1, 160000:] = 0.37; junk[2] = -0.2
+    got2 = m.log_mel(torch.from_numpy(junk).cuda(), lens=lens).cpu()
+    assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("name", ["whisper_base_cfg2"])
+def test_forward_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = GOLDEN_CASES[name]()
+    m, labels, sd_np = _build(cfg, int(g["n_phonemes"]), int(g["seed"]))
+    B, L = len(g["lang_id"]), int(g["L"])
+    wav = synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
+    thr = 0.5
+    out = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=thr, want_logits=True, want_hidden=True)
+    torch.cuda.synchronize()
+    r = g["rows"]
+    hid_err = np.abs(out.hidden.cpu().numpy()[:, r] - g["hidden_rows"])
+    lg_err = np.abs(out.logits.cpu().numpy()[:, r] - g["logits_rows"])
+    mp_err = np.abs(out.maxprob.cpu().numpy() - g["maxprob"])
+    of_err = np.abs(out.offsets.cpu().numpy() - g["offsets"])
+    o_id = labels.index("O")
+    ids_ref = np.where(g["maxprob"] < thr, o_id, g["argmax"].astype(np.int64))
+    safe = (g["margin"] > TAU) & (np.abs(g["maxprob"] - thr) > 0.08)
+    arg_bad = int((out.argmax.cpu().numpy() != g["argmax"])[g["margin"] > TAU].sum())
+    ids_bad = int((out.ids.cpu().numpy() != ids_ref)[safe].sum())
+    _note("golden_" + name, hidden_max=hid_err.max(), hidden_mean=hid_err.mean(), logits_max=lg_err.max(),
+          logits_mean=lg_err.mean(), maxprob_max=mp_err.max(), offsets_max=of_err.max(), safe_frac=safe.mean(),
+          argmax_bad=arg_bad, ids_bad=ids_bad, argmax_all_mismatch=int((out.argmax.cpu().numpy() != g["argmax"]).sum()))
+    assert hid_err.max() <= 0.08 and hid_err.mean() <= 0.012
+    assert lg_err.max() <= 0.6 and lg_err.mean() <= 0.08
+    assert mp_err.max() <= 0.08 and of_err.max() <= 0.03
+    assert arg_bad == 0 and ids_bad == 0 and safe.mean() >= 0.80
+
+
+def _tiny(**kw):
+    return tiny_whisper_config(enable_bilstm=False, **kw)
+
+
+def test_tiny_forward_vs_oracle_ragged_batch():
+    cfg = _tiny()
+    m, labels, sd_np = _build(cfg, 5, seed=21)
+    B, L = 3, 32000
+    lens = np.array([32000, 17000, 4000], np.int32)
+    wav = np.zeros((B, L), np.float32)
+    for i, n in enumerate(lens):
+        wav[i, :n] = synth.make_clip(300 + i, int(n), seed=21)
+    lang = np.array([0, 1, 0], np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, lens=lens, want_logits=True, want_hidden=True)
+    torch.cuda.synchronize()
+    lg, of, hid = _oracle(cfg, labels, sd_np, wav, lang)
+    h_err = (out.hidden.cpu() - hid).abs()
+    _note("tiny_hidden", max=h_err.max(), mean=h_err.mean())
+    assert h_err.max() <= 0.08
+    _check_decisions("tiny_ragged", out, lg, of, labels.index("O"), 0.5)
+
+
+def test_language_modes_vs_oracle():
+    cfg = _tiny(num_languages=3)
+    m, labels, sd_np = _build(cfg, 5, seed=22)
+    wav = synth.make_batch(400, 2, 20000, seed=22)
+    x = torch.from_numpy(wav).cuda()
+    # forward(lang_id=None): lang_proj skipped (model.py:176)
+    out = m.label(x, None, threshold=0.3, want_logits=True)
+    lg, of, _ = _oracle(cfg, labels, sd_np, wav, None)
+    _check_decisions("lang_none", out, lg, of, labels.index("O"), 0.3)
+    # infer.py:266-276: mean over every language id
+    out = m.label(x, None, threshold=0.3, average_languages=True, want_logits=True)
+    lgs, ofs = [], []
+    for lid in range(3):
+        a, b, _ = _oracle(cfg, labels, sd_np, wav, np.full(2, lid, np.int64))
+        lgs.append(a); ofs.append(b)
+    _check_decisions("lang_avg", out, torch.stack(lgs).mean(0), torch.stack(ofs).mean(0), labels.index("O"), 0.3)
+    with pytest.raises(ValueError):
+        m.label(x, [0, 3])
+
+
+def test_dilated_head_vs_oracle():
+    cfg = tiny_whisper_config(enable_bilstm=False, num_conformer_layers=1, dilated_conv_depth=3, dilated_conv_kernel=5)
+    m, labels, sd_np = _build(cfg, 5, seed=23)
+    wav = synth.make_batch(500, 2, 32000, seed=23)
+    lang = np.array([1, 0], np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True)
+    lg, of, _ = _oracle(cfg, labels, sd_np, wav, lang)
+    _check_decisions("dilated", out, lg, of, labels.index("O"), 0.5)
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE config 2 at its full size (16 x 30 s): properties that need no oracle run."""
+    cfg = synth.baseline_config(1)
+    m, labels, _ = _build(cfg, 70, seed=1)
+    B, L = 16, 480000
+    wav = synth.make_batch(2000, B, L, seed=1)
+    wav[5, 200000:] = 0.0
+    lang = (np.arange(B) % 2).astype(np.int64)
+    x = torch.from_numpy(wav).cuda()
+    full = m.label(x, lang, threshold=0.5, want_logits=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(full.logits).all()) and bool(torch.isfinite(full.offsets).all())
+    assert bool(((full.offsets >= 0) & (full.offsets <= 1)).all())
+    assert bool(((full.maxprob > 0) & (full.maxprob <= 1.0 + 1e-6)).all())
+    # decision rule holds frame by frame
+    want = torch.where(full.maxprob < 0.5, torch.full_like(full.argmax, labels.index("O")), full.argmax)
+    assert torch.equal(full.ids, want)
+    assert torch.equal(full.argmax.long(), full.logits.argmax(-1))
+    # batch invariance: a clip labelled alone / in a different batch slot gives bit-identical results
+    for i in (0, 5, 15):
+        one = m.label(x[i:i + 1], lang[i:i + 1], threshold=0.5, want_logits=True)
+        assert torch.equal(one.logits[0], full.logits[i]), i
+        assert torch.equal(one.offsets[0], full.offsets[i]) and torch.equal(one.ids[0], full.ids[i])
+    # Whisper pads to 30 s itself: a truncated clip == the same clip zero-padded (clip 5 is silent after 12.5 s)
+    short = m.label(x[5:6, :200000].contiguous(), lang[5:6], threshold=0.5, want_logits=True)
+    assert torch.equal(short.logits[0], full.logits[5])
+    # determinism
+    again = m.label(x, lang, threshold=0.5, want_logits=True)
+    assert torch.equal(again.logits, full.logits) and torch.equal(again.ids, full.ids)
+    _note("cfg2_full", distinct_tags=int(full.ids.unique().numel()), o_frac=float((full.ids == labels.index("O")).float().mean()))
+
+
+def test_errors_are_loud():
+    cfg = _tiny()
+    labels = synth.make_labels(5)
+    m = BIOPhonemeTagger(cfg, labels)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, len(labels), seed=1).items()}
+    bad = dict(sd); bad.pop("classifier.bias")
+    with pytest.raises(RuntimeError, match="missing key"):
+        BIOPhonemeTagger(cfg, labels).load_state_dict(bad)
+    bad = dict(sd); bad["extra.weight"] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        BIOPhonemeTagger(cfg, labels).load_state_dict(bad)
+    bad = dict(sd); bad["classifier.weight"] = torch.zeros(3, 64)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        BIOPhonemeTagger(cfg, labels).load_state_dict(bad)
+    with pytest.raises(RuntimeError):
+        m.label(torch.zeros(1, 100).cuda())                      # not loaded
+    m.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        m.label(torch.zeros(1, 100))                             # CPU tensor: no CPU path

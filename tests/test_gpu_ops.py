@@ -1,0 +1,207 @@
+"""-m gpu: each HIP kernel, called through the C ABI, against a plain PyTorch fp32 computation of the same op on
+the same bf16-rounded operands.  Tolerances are stated per test (bf16 output rounding = 2^-9 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _close(got, want, rtol=2e-2, atol=2e-2, what=""):
+    err = (got - want).abs()
+    lim = atol + rtol * want.abs()
+    assert bool((err <= lim).all()), f"{what}: max err {err.max().item():.4g}, worst excess {(err - lim).max().item():.4g}"
+
+
+@pytest.mark.parametrize("B,T,K,N", [(2, 200, 64, 128), (3, 301, 512, 512), (1, 1500, 256, 141), (16, 100, 2048, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_linear(B, T, K, N, act):
+    a = G.Rows(B, T, K).set(_rand(B, T, K, seed=1))
+    w, bias = _rand(N, K, scale=K ** -0.5, seed=2), _rand(N, scale=0.1, seed=3)
+    wp, bp = G.pad_weight(w, bias)
+    out = G.Rows(B, T, (N + 7) // 8 * 8)
+    G.gemm(a.buf, a.lead * K, K, wp, B * a.P, N, a.P, T, out.buf, out.C, out.lead, out.P, bias=bp, act=act)
+    torch.cuda.synchronize()
+    ref = a.get() @ _bf(w).T + bias
+    ref = [ref, F.gelu(ref), F.relu(ref), torch.sigmoid(ref)][act]
+    _close(out.get()[..., :N], ref, what="gemm")
+    assert out.halo_is_zero()
+    if out.C > N:
+        assert bool((out.get()[..., N:] == 0).all())
+
+
+def test_gemm_residual_alpha_inplace_and_f32():
+    B, T, K, N = 2, 333, 512, 512
+    a = G.Rows(B, T, K).set(_rand(B, T, K, seed=4))
+    x0 = _rand(B, T, N, seed=5)
+    x = G.Rows(B, T, N).set(x0)
+    w, bias = _rand(N, K, scale=K ** -0.5, seed=6), _rand(N, scale=0.1, seed=7)
+    wp, bp = G.pad_weight(w, bias)
+    G.gemm(a.buf, a.lead * K, K, wp, B * a.P, N, a.P, T, x.buf, N, x.lead, x.P, bias=bp, res=x.buf, ldres=N, alpha=0.5)
+    torch.cuda.synchronize()
+    ref = _bf(x0) + 0.5 * (a.get() @ _bf(w).T + bias)
+    _close(x.get(), ref, what="residual")
+    # fp32 compact output, ragged N (the classifier's shape)
+    Nc = 141
+    wc, bc = _rand(Nc, K, scale=0.3, seed=8), _rand(Nc, seed=9)
+    wcp, bcp = G.pad_weight(wc, bc)
+    lg = torch.full((B * T, Nc), float("nan"), device="cuda")
+    G.gemm(a.buf, a.lead * K, K, wcp, B * a.P, Nc, a.P, T, lg, Nc, 0, T, bias=bcp, out_f32=1)
+    torch.cuda.synchronize()
+    ref = (a.get() @ _bf(wc).T + bc).reshape(B * T, Nc)
+    _close(lg, ref, rtol=1e-3, atol=1e-3, what="f32 out")
+
+
+@pytest.mark.parametrize("C,k,dil", [(64, 3, 1), (512, 31, 1), (128, 3, 2), (64, 5, 4)])
+def test_gemm_conv_taps(C, k, dil):
+    B, T, N = 2, 257, 128
+    pad = dil * (k - 1) // 2
+    halo = max(16, (pad + 8) // 8 * 8)
+    x0 = _rand(B, T, C, seed=10)
+    a = G.Rows(B, T, C, halo=halo, lead=halo).set(x0)
+    w, bias = _rand(N, C, k, scale=(C * k) ** -0.5, seed=11), _rand(N, scale=0.1, seed=12)
+    rows = w.permute(0, 2, 1).reshape(N, k * C)                 # tap-major
+    wp, bp = G.pad_weight(rows, bias)
+    out = G.Rows(B, T, N, halo=halo, lead=halo)
+    if dil == 1:
+        G.gemm(a.buf, (a.lead - pad) * C, C, wp, B * a.P, N, a.P, T, out.buf, N, out.lead, out.P, bias=bp)
+    else:
+        G.gemm(a.buf, (a.lead - pad) * C, C, wp, B * a.P, N, a.P, T, out.buf, N, out.lead, out.P, bias=bp, cin=C, tap_stride=dil * C)
+    torch.cuda.synchronize()
+    ref = F.conv1d(_bf(x0).transpose(1, 2), _bf(w), bias, padding=pad, dilation=dil).transpose(1, 2)
+    _close(out.get(), ref, what="conv")
+
+
+def test_gemm_conv_stride2_and_pos():
+    # the Whisper stem's second conv: k3 s2 p1 on rows whose pitch is twice the output pitch, + positional table
+    B, T, C, N = 2, 150, 64, 128
+    out = G.Rows(B, T, N, halo=18, lead=16)            # P = 168
+    Tin, Pin = 2 * T, 2 * out.P
+    x0 = _rand(B, Tin, C, seed=13)
+    a = G.Rows(B, Tin, C, lead=8, pitch=Pin, tail=512).set(x0)
+    w, bias = _rand(N, C, 3, scale=(3 * C) ** -0.5, seed=14), _rand(N, scale=0.1, seed=15)
+    wp, bp = G.pad_weight(w.permute(0, 2, 1).reshape(N, 3 * C), bias)
+    pos = _rand(T, N, seed=16).to(torch.bfloat16)
+    lib = G.lib()
+    # pos is not part of wfl_op_gemm's surface; emulate with the residual input (same add, alpha = 1)
+    posrows = G.Rows(B, T, N, halo=18, lead=16).set(pos.float().expand(B, T, N))
+    G.gemm(a.buf, (a.lead - 1) * C, 2 * C, wp, B * out.P, N, out.P, T, out.buf, N, out.lead, out.P, bias=bp, act=1,
+           res=posrows.buf, ldres=N, alpha=1.0)
+    torch.cuda.synchronize()
+    ref = F.gelu(F.conv1d(_bf(x0).transpose(1, 2), _bf(w), bias, stride=2, padding=1)).transpose(1, 2) + pos.float()
+    _close(out.get(), ref, what="conv s2")
+
+
+def test_gemm_glu():
+    B, T, d = 2, 130, 128
+    x0 = _rand(B, T, d, seed=17)
+    a = G.Rows(B, T, d).set(x0)
+    w, bias = _rand(2 * d, d, scale=d ** -0.5, seed=18), _rand(2 * d, scale=0.2, seed=19)
+    rows = torch.empty_like(w)
+    brow = torch.empty_like(bias)
+    for g in range(d // 16):
+        rows[32 * g:32 * g + 16] = w[16 * g:16 * g + 16]
+        rows[32 * g + 16:32 * g + 32] = w[d + 16 * g:d + 16 * g + 16]
+        brow[32 * g:32 * g + 16] = bias[16 * g:16 * g + 16]
+        brow[32 * g + 16:32 * g + 32] = bias[d + 16 * g:d + 16 * g + 16]
+    wp, bp = G.pad_weight(rows, brow)
+    out = G.Rows(B, T, d)
+    G.gemm(a.buf, a.lead * d, d, wp, B * a.P, 2 * d, a.P, T, out.buf, d, out.lead, out.P, bias=bp, glu=1)
+    torch.cuda.synchronize()
+    ref = F.glu(a.get() @ _bf(w).T + bias, dim=-1)
+    _close(out.get(), ref, what="glu")
+
+
+@pytest.mark.parametrize("d,heads,T", [(64, 2, 100), (128, 2, 257), (512, 8, 1500), (512, 2, 300)])
+def test_qkv_projection_and_attention(d, heads, T):
+    """packed q|k|v GEMM (V written transposed) + flash attention vs softmax(q k^T / sqrt(hd)) v."""
+    B = 2
+    hd = d // heads
+    x0 = _rand(B, T, d, seed=20)
+    a = G.Rows(B, T, d).set(x0)
+    w, bias = _rand(3 * d, d, scale=d ** -0.5 * 2.0, seed=21), _rand(3 * d, scale=0.1, seed=22)
+    qs = hd ** -0.5 * math.log2(math.e)
+    wq = w.clone(); bq = bias.clone()
+    wq[:d] *= qs; bq[:d] *= qs
+    wp, bp = G.pad_weight(wq, bq)
+    qk = G.Rows(B, T, 2 * d)
+    vt = torch.zeros(B * d * a.P + 256, dtype=torch.bfloat16, device="cuda")
+    G.gemm(a.buf, a.lead * d, d, wp, B * a.P, 3 * d, a.P, T, qk.buf, 2 * d, qk.lead, qk.P, bias=bp, Vt=vt, vt_n0=2 * d)
+    torch.cuda.synchronize()
+    proj = a.get() @ _bf(wq).T + bq
+    _close(qk.get(), proj[..., :2 * d], what="q|k")
+    vt_view = vt[:B * d * a.P].view(B, d, a.P).float()
+    _close(vt_view[:, :, :T], proj[..., 2 * d:].transpose(1, 2), what="V^T")
+    assert bool((vt_view[:, :, T:] == 0).all())
+    o = G.Rows(B, T, d)
+    G.attention(qk.buf, 2 * d, qk.lead, vt, o.buf, d, B, T, a.P, heads, d)
+    torch.cuda.synchronize()
+    q = qk.get()[..., :d].view(B, T, heads, hd).transpose(1, 2) / math.log2(math.e)
+    k = qk.get()[..., d:].view(B, T, heads, hd).transpose(1, 2)
+    v = vt_view[:, :, :T].transpose(1, 2).reshape(B, T, heads, hd).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(2, 3), -1) @ v).transpose(1, 2).reshape(B, T, d)
+    _close(o.get(), ref, rtol=2e-2, atol=1e-2, what="attention")
+    assert o.halo_is_zero()
+
+
+def test_attention_peaked_softmax():
+    """a query row that matches one late key with a huge score (forces the online-softmax rescale path)."""
+    B, T, d, heads = 1, 200, 64, 1
+    q = _rand(B, T, d, seed=23) * 0.1
+    k = _rand(B, T, d, seed=24) * 0.1
+    v = _rand(B, T, d, seed=25)
+    k[0, 170] = 3.0
+    q[0, 5] = 3.0                       # score(5, 170) ~ 576 in log2 units; everything else ~0
+    qk = G.Rows(B, T, 2 * d).set(torch.cat([q, k], -1))
+    P = qk.P
+    vt = torch.zeros(B * d * P + 256, dtype=torch.bfloat16, device="cuda")
+    vt[:B * d * P].view(B, d, P)[:, :, :T] = v.transpose(1, 2).to(torch.bfloat16)
+    o = G.Rows(B, T, d)
+    G.attention(qk.buf, 2 * d, qk.lead, vt, o.buf, d, B, T, P, heads, d)
+    torch.cuda.synchronize()
+    s = (_bf(q) @ _bf(k).transpose(1, 2)) * math.log(2.0)
+    ref = torch.softmax(s, -1) @ _bf(v)
+    _close(o.get(), ref, rtol=2e-2, atol=1e-2, what="peaked attention")
+    _close(o.get()[0, 5], _bf(v)[0, 170], rtol=1e-2, atol=1e-2, what="one-hot row")
+
+
+@pytest.mark.parametrize("C", [64, 512, 768, 1280])
+def test_layernorm(C):
+    B, T = 3, 211
+    x0 = _rand(B, T, C, seed=26) * 3.0 + 0.7
+    x = G.Rows(B, T, C).set(x0)
+    y = G.Rows(B, T, C)
+    g, b = 1.0 + 0.1 * _rand(C, seed=27), 0.1 * _rand(C, seed=28)
+    G.layernorm(x.buf, y.buf, g, b, 1e-5, x.lead, B, x.P, T, C)
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.get(), (C,), g, b, 1e-5)
+    _close(y.get(), ref, rtol=1e-2, atol=1e-2, what="layernorm")
+    assert y.halo_is_zero()
+
+
+def test_tag_decide_exact():
+    rows, C_ = 3000, 141
+    logits = _rand(rows, C_, seed=29) * 4.0
+    logits[7, 3] = logits[7, 90] = 50.0            # tie -> first index
+    ids, arg, mp = G.tag_decide(logits, 0.5, 77)
+    torch.cuda.synchronize()
+    p = torch.softmax(logits, -1)
+    mref, aref = p.max(-1)
+    assert torch.equal(arg.long(), aref) and int(arg[7]) == 3
+    torch.testing.assert_close(mp, mref, rtol=2e-6, atol=2e-7)
+    sure = (mref - 0.5).abs() > 1e-5
+    want = torch.where(mref < 0.5, torch.full_like(aref, 77), aref)
+    assert torch.equal(ids.long()[sure], want[sure])

@@ -1,0 +1,236 @@
+// Flash-style self-attention for gfx950: softmax(q k^T) v per (clip, head), scores never materialised.
+// Replaces HF modeling_whisper.py:215-238 / SDPA (Whisper, head_dim 64) and nn.MultiheadAttention inside the
+// Conformer block (/root/reference/model.py:26, 42; head_dim = d / conformer_heads = 256 for Whisper-base).
+//
+// One workgroup = 4 waves = one (clip, head, block of query frames); each wave owns QT tiles of 16 query frames.
+// K tiles (64 keys x HD) and V^T tiles (HD x 64 keys; the QKV projection already wrote V transposed) are staged
+// in LDS.  Scores are computed TRANSPOSED, S^T = K . Q^T with MFMA 16x16x32 (A = K rows, B = Q rows), so every
+// lane holds scores of ONE query frame (column lane&15) and the row max/sum need only two cross-lane steps; the
+// S^T accumulators are then already laid out as the B operand of O^T = V^T . P^T (key order inside a 32-key
+// k-step is permuted identically for P and for the V^T fragment reads), so P never touches LDS.
+// q is pre-scaled by head_dim^-1/2 * log2(e) at weight-pack time, so the softmax is exp2(s - max).
+#include "common.h"
+
+#define KT 64          // keys per tile
+#define VPITCH 136     // bytes per V^T LDS row (64 keys * 2 + 8 pad): conflict-free ds_read_b64
+
+template <int HD>
+static __device__ __forceinline__ int k_swz(int row) {
+  constexpr int CPR = HD / 8;                 // 16-byte chunks per K row
+  if (CPR >= 16) return row & 15;
+  if (CPR == 8) return (row >> 1) & 7;
+  return (row >> 2) & 3;                      // CPR == 4
+}
+
+template <int HD, int QT, bool PREFETCH>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                       // [KT][HD] bf16, 16-byte chunks XOR-swizzled
+  char* Vs = smem + KT * HD * 2;         // [HD][VPITCH]
+  constexpr int CPR = HD / 8;
+  constexpr int KCH = KT * CPR / 256;    // K chunks per thread per tile
+  constexpr int VCH = HD * 8 / 256;      // V^T chunks per thread per tile
+  constexpr int KS = HD / 32;            // k-steps over head_dim
+  constexpr int DT = HD / 16;            // output channel tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (4 * QT * 16) + wid * (QT * 16);
+  const long row0 = p.lead + (long)b * p.P;
+  const bf16_t* Kg = p.QK + p.d + h * HD;                 // + row * ldqk
+  const bf16_t* Vg = p.Vt + ((long)b * p.d + h * HD) * p.P;
+
+  // ---- Q fragments (B operand): lane -> query frame q0 + 16*qt + c, channels 32*ks + 8*g .. +8
+  bf16x8 qf[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int q = q0 + qt * 16 + c;
+    q = q < p.T ? q : p.T - 1;
+    const bf16_t* qp = p.QK + (row0 + q) * p.ldqk + h * HD + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *(const bf16x8*)(qp + ks * 32);
+  }
+
+  f32x4 o[QT][DT];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = -INFINITY;
+    lrun[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int ntiles = (p.T + KT - 1) / KT;
+  bf16x8 kreg[KCH], vreg[VCH];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int ch = tid + 256 * i;
+      const int r = ch / CPR, cc = ch % CPR;
+      kreg[i] = *(const bf16x8*)(Kg + (row0 + kt * KT + r) * p.ldqk + cc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int ch = tid + 256 * i;
+      const int r = ch >> 3, cc = ch & 7;
+      vreg[i] = *(const bf16x8*)(Vg + (long)r * p.P + kt * KT + cc * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int ch = tid + 256 * i;
+      const int r = ch / CPR, cc = ch % CPR;
+      *(bf16x8*)(Ks + r * (HD * 2) + ((cc ^ k_swz<HD>(r)) << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int ch = tid + 256 * i;
+      const int r = ch >> 3, cc = ch & 7;
+      const bf16x4 lo = {vreg[i][0], vreg[i][1], vreg[i][2], vreg[i][3]};
+      const bf16x4 hi = {vreg[i][4], vreg[i][5], vreg[i][6], vreg[i][7]};
+      *(bf16x4*)(Vs + r * VPITCH + cc * 16) = lo;
+      *(bf16x4*)(Vs + r * VPITCH + cc * 16 + 8) = hi;
+    }
+  };
+
+  if (PREFETCH) load_tile(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();                     // every wave is done reading the previous tile
+    if (!PREFETCH) load_tile(kt);
+    store_tile();
+    __syncthreads();
+    if (PREFETCH && kt + 1 < ntiles) load_tile(kt + 1);   // in flight under this tile's MFMAs
+
+    // ---- S^T = K . Q^T : st[qt][kk][e] = score(query q0+16qt+c, key 64kt + 16kk + 4g + e)
+    f32x4 st[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) st[qt][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int r = kk * 16 + c;
+        const bf16x8 kf = *(const bf16x8*)(Ks + r * (HD * 2) + (((ks * 4 + g) ^ k_swz<HD>(r)) << 4));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          st[qt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kk], 0, 0, 0);
+      }
+    }
+    if (kt * KT + KT > p.T) {            // last tile: keys >= T do not exist
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kt * KT + kk * 16 + g * 4 + e >= p.T) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) st[qt][kk][e] = -INFINITY;
+          }
+    }
+
+    // ---- online softmax (per query frame = per lane column c; the 4 lane groups g share a frame)
+    bf16x8 pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = st[qt][0][0];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[qt][kk][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      mrun[qt] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(st[qt][kk][e] - mnew);
+          st[qt][kk][e] = pv;
+          ps += pv;
+        }
+      lrun[qt] = lrun[qt] * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          t[e] = f2bf(st[qt][2 * s2][e]);
+          t[4 + e] = f2bf(st[qt][2 * s2 + 1][e]);
+        }
+        pf[qt][s2] = t;
+      }
+    }
+
+    // ---- O^T += V^T . P^T : k-slot 8g+j of k-step s2 is key 32*s2 + 4g + j (j<4) / 32*s2 + 16 + 4g + j-4
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const char* vp = Vs + (dt * 16 + c) * VPITCH + (32 * s2 + 4 * g) * 2;
+        const bf16x4 lo = *(const bf16x4*)vp;
+        const bf16x4 hi = *(const bf16x4*)(vp + 32);
+        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds channels h*HD + 16dt + 4g + e of query frame q0 + 16qt + c
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = q0 + qt * 16 + c;
+    if (q < p.T) {
+      bf16_t* op = p.O + (row0 + q) * p.ldo + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[qt][dt][e] * inv);
+        *(bf16x4*)(op + dt * 16) = ov;
+      }
+    }
+  }
+}
+
+template <int HD, int QT, bool PREFETCH>
+static int launch_attn(const AttnArgs& a, hipStream_t s) {
+  constexpr int lds = KT * HD * 2 + HD * VPITCH;
+  auto k = attn_kernel<HD, QT, PREFETCH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+    attr_set = true;
+  }
+  const int qb = 4 * QT * 16;
+  dim3 grid((a.T + qb - 1) / qb, a.heads, a.B);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
+  if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldo % 4 || a.T <= 0) return -1;
+  const int hd = a.d / a.heads;
+  switch (hd) {
+    case 32: return launch_attn<32, 2, true>(a, s);
+    case 64: return launch_attn<64, 2, true>(a, s);
+    case 128: return launch_attn<128, 2, true>(a, s);
+    case 256: return launch_attn<256, 1, false>(a, s);
+  }
+  return -4;   // unsupported head_dim
+}

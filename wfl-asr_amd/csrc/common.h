@@ -1,0 +1,89 @@
+// Shared device/host definitions for the gfx950 kernels of the WFL-ASR labeling hot path.
+//
+// HBM layout of every activation ("frame rows"): a flat run of rows, C channels each, bf16:
+//
+//     row(b, t) = lead + b * pitch + t          0 <= t < T,   pitch = T + halo  (pitch % 8 == 0)
+//
+// Rows outside [0, T) of a clip (the `halo` rows between clips, the `lead` rows in front of clip 0 and the
+// slack behind the last clip) are ZERO and are never written by any kernel, so a k-tap Conv1d over time is a
+// plain GEMM whose A row for output frame t is the contiguous run of k*C channels starting at frame t - pad
+// (channels-last makes the taps adjacent), a stride-s conv is the same GEMM with lda = s*C reading a buffer
+// whose pitch is s times the output pitch, and tiles may straddle clips: a kernel walks the flat row index m,
+// and only decides `m % pitch < T` when it stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WFL_ACT_NONE 0
+#define WFL_ACT_GELU 1
+#define WFL_ACT_RELU 2
+#define WFL_ACT_SIGMOID 3
+
+// One bf16 GEMM launch:  C[m][n] = epi( sum_k A(m, k) * W[n][k] )
+struct GemmArgs {
+  const bf16_t* A;      // row m starts at A + m * lda
+  long lda;             // elements
+  int cin;              // channels per tap; k -> tap = k / cin, c = k % cin, at +tap * tap_stride + c
+  long tap_stride;      // elements between taps (= dilation * C of the input buffer); cin >= K => single tap
+  const bf16_t* W;      // [N][K] row-major, N % 128 == 0, K % 64 == 0 (zero padded)
+  int M, N, K;
+  int n_valid;          // columns >= n_valid are not stored
+  int P, T;             // flat row m -> clip b = m / P, frame t = m % P, stored iff t < T
+  void* C;              // output rows: C + (c_lead + b * c_pitch + t) * ldc
+  long ldc;
+  long c_lead;
+  int c_pitch;
+  const float* bias;        // [N] or null
+  const float* clip_bias;   // [n_clip_rows][clip_ld] per-clip additive bias table or null
+  const int* clip_idx;      // [B] row of clip_bias used by clip b
+  int clip_ld;
+  const bf16_t* res;        // residual, same row mapping as C, or null
+  long ldres;
+  float alpha;              // out = res + alpha * act(v)
+  const bf16_t* pos;        // [T][ldpos] added after the activation (positional table) or null
+  long ldpos;
+  int act;
+  int glu;                  // weights row-interleaved in groups of 16 (a | gate); N_out = N / 2
+  int out_f32;
+  bf16_t* Vt;               // columns >= vt_n0 are written transposed: Vt[(b * (N - vt_n0) + n - vt_n0) * P + t]
+  int vt_n0;                // (multiple of 128); frames t in [T, P) of Vt are written as zero
+};
+
+struct AttnArgs {
+  const bf16_t* QK;   // frame rows, ld = ldqk: [q (d) | k (d)] per row, q pre-scaled by hd^-1/2 * log2(e)
+  long ldqk;
+  long lead;          // row(b,t) = lead + b*P + t
+  const bf16_t* Vt;   // [B][heads*hd][P]
+  bf16_t* O;          // frame rows, ld = ldo, head h at column h*hd
+  long ldo;
+  int B, T, P, heads, d;
+  const float* bias;      // optional additive score bias (WavLM gated rel-pos), see attention.hip
+  const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
+};
+
+static __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+static __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int ACT>
+static __device__ __forceinline__ float apply_act(float v) {
+  if (ACT == WFL_ACT_GELU) return gelu_erf(v);
+  if (ACT == WFL_ACT_RELU) return fmaxf(v, 0.0f);
+  if (ACT == WFL_ACT_SIGMOID) return sigmoidf_(v);
+  return v;
+}
+
+static __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+static __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+// host-side launchers (one per .hip translation unit)
+int wfl_launch_gemm(const GemmArgs& a, hipStream_t s);
+int wfl_launch_attention(const AttnArgs& a, hipStream_t s);
+int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
+                         long lead, int B, int P, int T, int C, hipStream_t s);
+int wfl_launch_zero_halo(bf16_t* buf, long ld_bytes, long lead, int B, int P, int T, long tail_rows, hipStream_t s);

@@ -1,0 +1,153 @@
+// Whisper log-mel front-end on gfx950, fp32 end to end.  Replaces the CPU round trip at
+// /root/reference/model.py:153-154 (HF feature_extraction_whisper.py:135-168, 300-307): zero-pad/truncate to
+// n_samples, centred STFT (n_fft 400, hop 160, periodic Hann, reflect pad 200), power, Slaney mel, log10
+// (clamp 1e-10), per-clip floor (max - 8), (x + 4) / 4.
+//
+// Kernel 1 (one workgroup = 64 frames of one clip): the 400-point real DFT is a GEMM
+//   [64 frames x 400 samples] . [400 x 2*201 (Hann-folded cos | -sin)]
+// run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, so fp32 like torch.stft).
+// The frames operand is Toeplitz (frame f, sample n = signal[160 f + n]), so the workgroup stages only the
+// 10 480-sample signal segment in LDS, skewed by one word per 160 samples so that the 32 frames a fragment
+// read touches fall in 32 different banks.  Power spectra go through LDS to the sparse mel projection
+// (each bin feeds <= 2 triangles), log10, and an ordered-int atomic max per clip.
+// Kernel 2 applies the per-clip floor + affine and writes bf16 channels-last frame rows (the Whisper stem's
+// GEMM operand) and, for parity tests, an optional fp32 copy in the reference's [B, n_mels, frames] layout.
+#include "common.h"
+
+#define NFFT 400
+#define HOP 160
+#define NBIN_PAD 224     // 201 bins padded to 7 MFMA column tiles
+#define FT 64            // frames per workgroup
+#define SEG (63 * HOP + NFFT)              // 10480 samples
+#define SEG_LDS (SEG + SEG / HOP + 2)      // skewed
+#define PPITCH 225
+
+struct LogmelArgs {
+  const float* wav; long ldw;       // [B][ldw]
+  const int* lens;                  // [B] valid samples per clip, or null (=L)
+  int L;                            // samples present per row
+  int B, n_samples, n_frames, n_mels;
+  const float* Wc; const float* Ws; // [400][224]
+  const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
+  float* raw;                       // [B][n_frames][n_mels] log10 mel
+  unsigned* clipmax;                // [B] ordered-uint max of raw (zeroed by the caller)
+};
+
+static __device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static __device__ __forceinline__ float ord2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* seg = (float*)smem;
+  float* pw = seg + ((SEG_LDS + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, f0 = blockIdx.x * FT;
+  const int len = p.lens ? min(p.lens[b], min(p.L, p.n_samples)) : min(p.L, p.n_samples);
+  const float* w = p.wav + (long)b * p.ldw;
+
+  // ---- stage the signal segment: sample index i = 160*f0 - 200 + j, reflect about 0 and n_samples-1
+  const int s0 = f0 * HOP - NFFT / 2;
+  for (int j = tid; j < SEG; j += 256) {
+    int i = s0 + j;
+    if (i < 0) i = -i;
+    if (i >= p.n_samples) i = 2 * (p.n_samples - 1) - i;
+    const float v = (i >= 0 && i < len) ? w[i] : 0.f;
+    seg[j + j / HOP] = v;
+  }
+  __syncthreads();
+
+  // ---- DFT on the fp32 MFMA.  Lane l: A[row = l&31][k = l>>5], B[k = l>>5][col = l&31].
+  const int r = lane & 31, kh = lane >> 5;
+  for (int ct = wid; ct < NBIN_PAD / 32; ct += 4) {
+    f32x16 re[2], im[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { re[rt][e] = 0.f; im[rt][e] = 0.f; }
+    const float* a0 = seg + 161 * r + kh;                 // frame r of row tile 0
+    const float* a1 = seg + 161 * (r + 32) + kh;
+    const float* bc = p.Wc + (long)kh * NBIN_PAD + ct * 32 + r;
+    const float* bs = p.Ws + (long)kh * NBIN_PAD + ct * 32 + r;
+    // the skew term (n / 160) is constant on [0,160), [160,320), [320,400): three loops, no per-step compare
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      const int nb = part * 160, ne = part == 2 ? NFFT : nb + 160;
+#pragma unroll 8
+      for (int n = nb; n < ne; n += 2) {
+        const float x0 = a0[n + part], x1 = a1[n + part];
+        const float c = bc[(long)n * NBIN_PAD], s = bs[(long)n * NBIN_PAD];
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, c, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, s, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, c, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, s, im[1], 0, 0, 0);
+      }
+    }
+    // D[row][col]: col = lane&31 (bin), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (frame in the row tile)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int fr = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        pw[fr * PPITCH + ct * 32 + r] = re[rt][e] * re[rt][e] + im[rt][e] * im[rt][e];
+      }
+  }
+  __syncthreads();
+
+  // ---- sparse mel projection + log10; thread -> frame (tid & 63), mel bands (tid >> 6) + 4*i
+  const int f = tid & 63;
+  const bool fvalid = f0 + f < p.n_frames;
+  float mx = -INFINITY;
+  for (int m = tid >> 6; m < p.n_mels; m += 4) {
+    const int lo = p.mel_lo[m], cnt = p.mel_cnt[m];
+    const float* mw = p.mel_w + (long)m * p.mel_maxw;
+    float acc = 0.f;
+    for (int i = 0; i < cnt; ++i) acc += mw[i] * pw[f * PPITCH + lo + i];
+    const float lv = log10f(fmaxf(acc, 1e-10f));
+    if (fvalid) {
+      p.raw[((long)b * p.n_frames + f0 + f) * p.n_mels + m] = lv;
+      mx = fmaxf(mx, lv);
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+  if (lane == 0 && mx > -INFINITY) atomicMax(p.clipmax + b, f2ord(mx));
+}
+
+__global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restrict__ raw, const unsigned* __restrict__ clipmax,
+                                                            int B, int n_frames, int n_mels, bf16_t* __restrict__ out,
+                                                            long ldo, long lead, int P, float* __restrict__ ref_out) {
+  const long total = (long)B * n_frames * n_mels;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i % n_mels);
+    const long bf = i / n_mels;
+    const int t = (int)(bf % n_frames), b = (int)(bf / n_frames);
+    const float floorv = ord2f(clipmax[b]) - 8.0f;
+    const float v = (fmaxf(raw[i], floorv) + 4.0f) / 4.0f;
+    if (out) out[(lead + (long)b * P + t) * ldo + m] = f2bf(v);
+    if (ref_out) ref_out[((long)b * n_mels + m) * n_frames + t] = v;
+  }
+}
+
+int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s) {
+  if (a.n_frames * HOP != a.n_samples || a.n_mels <= 0 || a.B <= 0) return -1;
+  constexpr int lds = (((SEG_LDS + 3) & ~3) + FT * PPITCH) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)logmel_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+    attr_set = true;
+  }
+  if (hipMemsetAsync(a.clipmax, 0, sizeof(unsigned) * a.B, s) != hipSuccess) return -3;
+  dim3 grid((a.n_frames + FT - 1) / FT, a.B);
+  hipLaunchKernelGGL(logmel_power_kernel, grid, dim3(256), lds, s, a);
+  const long total = (long)a.B * a.n_frames * a.n_mels;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(logmel_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.raw, a.clipmax, a.B, a.n_frames,
+                     a.n_mels, out, ldo, lead, P, ref_out);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,840 @@
+// Model handle, weight packing and the forward schedule behind the C ABI of include/wfl_asr.h.
+//
+// This file is the native replacement for BIOPhonemeTagger (/root/reference/model.py:54-201): it owns the packed
+// bf16 weights in HBM, lays the caller's workspace out as frame-row buffers (common.h) and enqueues the kernel
+// sequence of one batched forward on the caller's HIP stream.  No torch types, no allocation and no
+// synchronisation inside wfl_forward (graph-capturable).
+#include "common.h"
+#include "../../include/wfl_asr.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+// ---- launchers defined in the kernel translation units
+struct LogmelArgs {
+  const float* wav; long ldw;
+  const int* lens;
+  int L;
+  int B, n_samples, n_frames, n_mels;
+  const float* Wc; const float* Ws;
+  const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
+  float* raw;
+  unsigned* clipmax;
+};
+int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s);
+
+struct TagArgs {
+  const float* logits; long ldl;
+  int rows, C;
+  float threshold; int o_id;
+  int* ids;
+  int* argmax;
+  float* maxprob;
+  const bf16_t* hid; long ldh; long lead; int P, T, d;
+  const float* w2;
+  const float* b2;
+  float* offsets;
+};
+int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
+int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
+int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s);
+int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                            \
+  do {                                                                                       \
+    hipError_t e_ = (x);                                                                     \
+    if (e_ != hipSuccess) return fail(-10, std::string(#x) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+static inline uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  long numel() const { long n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+// A packed Linear / Conv-as-GEMM operand
+struct Lin {
+  bf16_t* W = nullptr;   // [N][K] padded
+  float* bias = nullptr; // [N] padded (may be null)
+  int N = 0, K = 0, n_valid = 0;
+};
+struct LNp { float* g = nullptr; float* b = nullptr; };
+
+struct EncLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2; };
+struct ConfLayer {
+  LNp ff1_ln, ff2_ln, ln1, ln2;
+  Lin ff1_a, ff1_b, ff2_a, ff2_b, qkv, out, pw1, conv, pw2;
+};
+
+// GEMM launches are timed per kernel variant (template instantiation), keyed act | glu<<3 | out_f32<<4 | vt<<5
+struct GemmProf {
+  long launches[64] = {0};
+  double flops[64] = {0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<int> key;
+};
+
+struct wfl_model {
+  wfl_arch a{};
+  bool finalized = false;
+  std::map<std::string, HostTensor> host;
+  std::vector<void*> dev_allocs;
+  // geometry
+  int halo = 16;
+  // whisper front-end tables
+  float *Wc = nullptr, *Ws = nullptr, *mel_w = nullptr;
+  int *mel_lo = nullptr, *mel_cnt = nullptr;
+  int mel_maxw = 0;
+  Lin conv1, conv2;
+  bf16_t* pos = nullptr;
+  std::vector<EncLayer> enc;
+  LNp enc_ln;
+  // head
+  Lin lang;
+  float* lang_table = nullptr;    // [num_languages][d]
+  std::vector<ConfLayer> conf;
+  std::vector<Lin> dil;
+  Lin cls, off1;
+  float *off_w2 = nullptr, *off_b2 = nullptr;
+  // profiling
+  bool prof_on = false;
+  GemmProf prof;
+  size_t prof_used = 0;
+};
+
+const char* wfl_last_error(void) { return g_err.c_str(); }
+int32_t wfl_abi_version(void) { return WFL_ABI_VERSION; }
+
+int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
+  if (!arch || !out) return fail(-1, "wfl_create: null argument");
+  if (arch->abi_version != WFL_ABI_VERSION) return fail(-1, "wfl_create: ABI version mismatch");
+  const wfl_arch& a = *arch;
+  if (a.encoder_type != WFL_ENC_WHISPER && a.encoder_type != WFL_ENC_WAVLM) return fail(-1, "unknown encoder_type");
+  if (a.d_model <= 0 || a.d_model % 64) return fail(-1, "d_model must be a positive multiple of 64");
+  if (a.enc_heads <= 0 || a.d_model % a.enc_heads) return fail(-1, "enc_heads must divide d_model");
+  if (a.num_classes <= 0 || a.o_id < 0 || a.o_id >= a.num_classes) return fail(-1, "bad num_classes / o_id");
+  if (a.n_conformer > 0 && (a.conformer_heads <= 0 || a.d_model % a.conformer_heads)) return fail(-1, "bad conformer_heads");
+  if (a.n_conformer > 0 && a.conformer_kernel % 2 == 0) return fail(-1, "even conformer_kernel_size is not supported");
+  if (a.enable_dilated && a.dilated_kernel % 2 == 0) return fail(-1, "even dilated_conv_kernel is not supported");
+  wfl_model* m = new wfl_model();
+  m->a = a;
+  int pad = 1;
+  if (a.n_conformer > 0) pad = std::max(pad, a.conformer_kernel / 2);
+  if (a.enable_dilated)
+    for (int i = 0; i < a.dilated_depth; ++i) pad = std::max(pad, (1 << i) * (a.dilated_kernel - 1) / 2);
+  m->halo = (int)round_up(pad + 1, 8);
+  *out = m;
+  return 0;
+}
+
+void wfl_destroy(wfl_model* m) {
+  if (!m) return;
+  for (void* p : m->dev_allocs) (void)hipFree(p);
+  for (auto& e : m->prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete m;
+}
+
+int32_t wfl_load_tensor(wfl_model* m, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!m || !name || (!data && ndim > 0)) return fail(-1, "wfl_load_tensor: null argument");
+  if (m->finalized) return fail(-1, "wfl_load_tensor: model already finalized");
+  HostTensor t;
+  long n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+  if (data) t.data.assign(data, data + n);
+  m->host[name] = std::move(t);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ packing helpers
+namespace {
+
+struct Packer {
+  wfl_model* m;
+  std::set<std::string> used;
+  std::string err;
+
+  const HostTensor* get(const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = m->host.find(name);
+    if (it == m->host.end()) { if (err.empty()) err = "missing key in state_dict: " + name; return nullptr; }
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+      if (err.empty()) {
+        err = "size mismatch for " + name + ": got [";
+        for (auto s : it->second.shape) err += std::to_string(s) + ",";
+        err += "] expected [";
+        for (auto s : want) err += std::to_string(s) + ",";
+        err += "]";
+      }
+      return nullptr;
+    }
+    used.insert(name);
+    return &it->second;
+  }
+
+  template <class T>
+  T* upload(const std::vector<T>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(v.size() * sizeof(T), 16)) != hipSuccess) { if (err.empty()) err = "hipMalloc failed"; return nullptr; }
+    m->dev_allocs.push_back(d);
+    if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+      if (err.empty()) err = "hipMemcpy failed";
+      return nullptr;
+    }
+    return (T*)d;
+  }
+
+  // rows[n][k] fp32 (n_valid x k_valid) -> padded bf16 [N][K] + fp32 bias [N]
+  Lin pack(const std::vector<float>& rows, int n_valid, int k_valid, const std::vector<float>* bias) {
+    Lin L;
+    L.n_valid = n_valid;
+    L.N = (int)round_up(n_valid, 128);
+    L.K = (int)round_up(k_valid, 64);
+    std::vector<uint16_t> w((size_t)L.N * L.K, 0);
+    for (int n = 0; n < n_valid; ++n)
+      for (int k = 0; k < k_valid; ++k) w[(size_t)n * L.K + k] = f32_to_bf16_bits(rows[(size_t)n * k_valid + k]);
+    L.W = (bf16_t*)upload(w);
+    std::vector<float> b((size_t)L.N, 0.f);
+    if (bias) for (int n = 0; n < n_valid; ++n) b[n] = (*bias)[n];
+    L.bias = upload(b);
+    return L;
+  }
+
+  Lin linear(const std::string& p, int out_f, int in_f, bool has_bias = true) {
+    const HostTensor* w = get(p + ".weight", {out_f, in_f});
+    const HostTensor* b = has_bias ? get(p + ".bias", {out_f}) : nullptr;
+    if (!w || (has_bias && !b)) return Lin();
+    return pack(w->data, out_f, in_f, has_bias ? &b->data : nullptr);
+  }
+
+  // Conv1d weight [cout][cin][k] -> tap-major rows [cout][k*cin]; optional per-output-channel scale/shift (BN fold)
+  Lin conv(const std::string& p, int cout, int cin, int k, const std::vector<float>* scale = nullptr,
+           const std::vector<float>* shift = nullptr, bool has_bias = true) {
+    const HostTensor* w = get(p + ".weight", {cout, cin, k});
+    const HostTensor* b = has_bias ? get(p + ".bias", {cout}) : nullptr;
+    if (!w || (has_bias && !b)) return Lin();
+    std::vector<float> rows((size_t)cout * k * cin), bias(cout, 0.f);
+    for (int co = 0; co < cout; ++co) {
+      const float sc = scale ? (*scale)[co] : 1.f;
+      for (int ci = 0; ci < cin; ++ci)
+        for (int j = 0; j < k; ++j) rows[((size_t)co * k + j) * cin + ci] = w->data[((size_t)co * cin + ci) * k + j] * sc;
+      float bv = has_bias ? b->data[co] : 0.f;
+      bias[co] = bv * sc + (shift ? (*shift)[co] : 0.f);
+    }
+    return pack(rows, cout, k * cin, &bias);
+  }
+
+  LNp ln(const std::string& p, int d) {
+    LNp r;
+    const HostTensor* g = get(p + ".weight", {d});
+    const HostTensor* b = get(p + ".bias", {d});
+    if (!g || !b) return r;
+    r.g = upload(g->data);
+    r.b = upload(b->data);
+    return r;
+  }
+};
+
+// Slaney mel filter bank, as HF audio_utils.py:638-729 with feature_extraction_whisper.py:97-105's arguments
+// (0..8000 Hz, 201 bins, norm="slaney", mel_scale="slaney"); float64 then rounded to fp32 like the reference.
+static void build_mel(int n_mels, std::vector<int>& lo, std::vector<int>& cnt, std::vector<float>& w, int& maxw) {
+  const int nf = 201;
+  auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4)) : 3.0 * f / 200.0; };
+  auto mel2hz = [](double mm) { return mm >= 15.0 ? 1000.0 * std::exp((std::log(6.4) / 27.0) * (mm - 15.0)) : 200.0 * mm / 3.0; };
+  const double m0 = hz2mel(0.0), m1 = hz2mel(8000.0);
+  std::vector<double> ff(n_mels + 2);
+  for (int i = 0; i < n_mels + 2; ++i) ff[i] = mel2hz(m0 + (m1 - m0) * i / (n_mels + 1));
+  std::vector<std::vector<float>> fb(n_mels, std::vector<float>(nf, 0.f));
+  for (int k = 0; k < nf; ++k) {
+    const double f = 8000.0 * k / (nf - 1);
+    for (int i = 0; i < n_mels; ++i) {
+      const double down = (f - ff[i]) / (ff[i + 1] - ff[i]);
+      const double up = (ff[i + 2] - f) / (ff[i + 2] - ff[i + 1]);
+      const double v = std::max(0.0, std::min(down, up)) * (2.0 / (ff[i + 2] - ff[i]));
+      fb[i][k] = (float)v;
+    }
+  }
+  lo.assign(n_mels, 0);
+  cnt.assign(n_mels, 0);
+  maxw = 1;
+  for (int i = 0; i < n_mels; ++i) {
+    int a = nf, b = -1;
+    for (int k = 0; k < nf; ++k)
+      if (fb[i][k] != 0.f) { a = std::min(a, k); b = std::max(b, k); }
+    if (b >= a) { lo[i] = a; cnt[i] = b - a + 1; maxw = std::max(maxw, cnt[i]); }
+  }
+  w.assign((size_t)n_mels * maxw, 0.f);
+  for (int i = 0; i < n_mels; ++i)
+    for (int j = 0; j < cnt[i]; ++j) w[(size_t)i * maxw + j] = fb[i][lo[i] + j];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ finalize
+static int finalize_whisper(wfl_model* m, Packer& P) {
+  const wfl_arch& a = m->a;
+  const int d = a.d_model, hd = d / a.enc_heads;
+  // front-end tables: Hann-folded DFT matrix (periodic Hann as torch.hann_window(400))
+  {
+    std::vector<float> wc((size_t)400 * 224, 0.f), ws((size_t)400 * 224, 0.f);
+    for (int n = 0; n < 400; ++n) {
+      const double hann = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / 400.0);
+      for (int k = 0; k <= 200; ++k) {
+        const int nk = (int)(((long)n * k) % 400);
+        const double ang = 2.0 * M_PI * nk / 400.0;
+        wc[(size_t)n * 224 + k] = (float)(hann * std::cos(ang));
+        ws[(size_t)n * 224 + k] = (float)(-hann * std::sin(ang));
+      }
+    }
+    m->Wc = P.upload(wc);
+    m->Ws = P.upload(ws);
+    std::vector<int> lo, cnt;
+    std::vector<float> w;
+    build_mel(a.n_mels, lo, cnt, w, m->mel_maxw);
+    m->mel_lo = P.upload(lo);
+    m->mel_cnt = P.upload(cnt);
+    m->mel_w = P.upload(w);
+  }
+  m->conv1 = P.conv("encoder.conv1", d, a.n_mels, 3);
+  m->conv2 = P.conv("encoder.conv2", d, d, 3);
+  if (const HostTensor* pe = P.get("encoder.embed_positions.weight", {a.max_positions, d})) {
+    std::vector<uint16_t> pb(pe->data.size());
+    for (size_t i = 0; i < pb.size(); ++i) pb[i] = f32_to_bf16_bits(pe->data[i]);
+    m->pos = (bf16_t*)P.upload(pb);
+  }
+  const float qs = (float)(std::pow((double)hd, -0.5) * 1.4426950408889634);   // hd^-1/2 * log2(e)
+  m->enc.resize(a.enc_layers);
+  for (int i = 0; i < a.enc_layers; ++i) {
+    const std::string p = "encoder.layers." + std::to_string(i) + ".";
+    EncLayer& L = m->enc[i];
+    L.ln1 = P.ln(p + "self_attn_layer_norm", d);
+    L.ln2 = P.ln(p + "final_layer_norm", d);
+    const HostTensor* wq = P.get(p + "self_attn.q_proj.weight", {d, d});
+    const HostTensor* bq = P.get(p + "self_attn.q_proj.bias", {d});
+    const HostTensor* wk = P.get(p + "self_attn.k_proj.weight", {d, d});
+    const HostTensor* wv = P.get(p + "self_attn.v_proj.weight", {d, d});
+    const HostTensor* bv = P.get(p + "self_attn.v_proj.bias", {d});
+    if (wq && bq && wk && wv && bv) {
+      std::vector<float> rows((size_t)3 * d * d), bias((size_t)3 * d, 0.f);
+      for (size_t j = 0; j < (size_t)d * d; ++j) {
+        rows[j] = wq->data[j] * qs;
+        rows[(size_t)d * d + j] = wk->data[j];
+        rows[(size_t)2 * d * d + j] = wv->data[j];
+      }
+      for (int j = 0; j < d; ++j) { bias[j] = bq->data[j] * qs; bias[2 * d + j] = bv->data[j]; }
+      L.qkv = P.pack(rows, 3 * d, d, &bias);
+    }
+    L.out = P.linear(p + "self_attn.out_proj", d, d);
+    L.fc1 = P.linear(p + "fc1", a.enc_ffn, d);
+    L.fc2 = P.linear(p + "fc2", d, a.enc_ffn);
+  }
+  m->enc_ln = P.ln("encoder.layer_norm", d);
+  return 0;
+}
+
+static int finalize_head(wfl_model* m, Packer& P) {
+  const wfl_arch& a = m->a;
+  const int d = a.d_model, e = a.lang_emb_dim;
+  // language conditioning: cat(h, emb) @ W^T + b  ==  h @ W[:, :d]^T + (W[:, d:] @ emb + b)   (model.py:176-180)
+  const HostTensor* emb = P.get("lang_emb.weight", {a.num_languages, e});
+  const HostTensor* lw = P.get("lang_proj.weight", {d, d + e});
+  const HostTensor* lb = P.get("lang_proj.bias", {d});
+  if (emb && lw && lb) {
+    std::vector<float> rows((size_t)d * d), table((size_t)std::max(a.num_languages, 1) * d, 0.f);
+    for (int n = 0; n < d; ++n) {
+      for (int k = 0; k < d; ++k) rows[(size_t)n * d + k] = lw->data[(size_t)n * (d + e) + k];
+      for (int l = 0; l < a.num_languages; ++l) {
+        double acc = lb->data[n];
+        for (int k = 0; k < e; ++k) acc += (double)lw->data[(size_t)n * (d + e) + d + k] * emb->data[(size_t)l * e + k];
+        table[(size_t)l * d + n] = (float)acc;
+      }
+    }
+    m->lang = P.pack(rows, d, d, nullptr);
+    m->lang_table = P.upload(table);
+  }
+  if (a.enable_bilstm) { if (P.err.empty()) P.err = "BiLSTM head is not built into this library yet"; }
+  m->conf.resize(a.n_conformer);
+  const int x = a.conformer_ff_expansion, kk = a.conformer_kernel;
+  for (int i = 0; i < a.n_conformer; ++i) {
+    const std::string p = "conformer_layers." + std::to_string(i) + ".";
+    ConfLayer& C = m->conf[i];
+    C.ff1_ln = P.ln(p + "ff1.net.0", d);
+    C.ff1_a = P.linear(p + "ff1.net.1", d * x, d);
+    C.ff1_b = P.linear(p + "ff1.net.4", d, d * x);
+    C.ff2_ln = P.ln(p + "ff2.net.0", d);
+    C.ff2_a = P.linear(p + "ff2.net.1", d * x, d);
+    C.ff2_b = P.linear(p + "ff2.net.4", d, d * x);
+    const HostTensor* iw = P.get(p + "self_attn.in_proj_weight", {3 * d, d});
+    const HostTensor* ib = P.get(p + "self_attn.in_proj_bias", {3 * d});
+    if (iw && ib) {
+      const int hd = d / a.conformer_heads;
+      const float qs = (float)(std::pow((double)hd, -0.5) * 1.4426950408889634);
+      std::vector<float> rows(iw->data), bias(ib->data);
+      for (size_t j = 0; j < (size_t)d * d; ++j) rows[j] *= qs;
+      for (int j = 0; j < d; ++j) bias[j] *= qs;
+      C.qkv = P.pack(rows, 3 * d, d, &bias);
+    }
+    C.out = P.linear(p + "self_attn.out_proj", d, d);
+    C.ln1 = P.ln(p + "ln1", d);
+    C.ln2 = P.ln(p + "ln2", d);
+    // pointwise conv d -> 2d followed by GLU: interleave rows in groups of 16 (a | gate)
+    const HostTensor* pw = P.get(p + "conv.0.weight", {2 * d, d, 1});
+    const HostTensor* pb = P.get(p + "conv.0.bias", {2 * d});
+    if (pw && pb) {
+      std::vector<float> rows((size_t)2 * d * d), bias((size_t)2 * d);
+      for (int gidx = 0; gidx < d / 16; ++gidx)
+        for (int r = 0; r < 16; ++r) {
+          const int ca = gidx * 16 + r, cg = d + gidx * 16 + r;
+          const int ra = gidx * 32 + r, rg = gidx * 32 + 16 + r;
+          memcpy(&rows[(size_t)ra * d], &pw->data[(size_t)ca * d], sizeof(float) * d);
+          memcpy(&rows[(size_t)rg * d], &pw->data[(size_t)cg * d], sizeof(float) * d);
+          bias[ra] = pb->data[ca];
+          bias[rg] = pb->data[cg];
+        }
+      C.pw1 = P.pack(rows, 2 * d, d, &bias);
+    }
+    // dense k-tap conv with eval-mode BatchNorm folded in: y = (conv(x) - mean) * g / sqrt(var + eps) + beta
+    const HostTensor* bw = P.get(p + "conv.3.weight", {d});
+    const HostTensor* bb = P.get(p + "conv.3.bias", {d});
+    const HostTensor* bm = P.get(p + "conv.3.running_mean", {d});
+    const HostTensor* bvar = P.get(p + "conv.3.running_var", {d});
+    if (m->host.count(p + "conv.3.num_batches_tracked")) P.used.insert(p + "conv.3.num_batches_tracked");
+    if (bw && bb && bm && bvar) {
+      std::vector<float> sc(d), sh(d);
+      for (int c = 0; c < d; ++c) {
+        sc[c] = bw->data[c] / std::sqrt(bvar->data[c] + 1e-5f);
+        sh[c] = bb->data[c] - bm->data[c] * sc[c];
+      }
+      C.conv = P.conv(p + "conv.2", d, d, kk, &sc, &sh);
+    }
+    C.pw2 = P.conv(p + "conv.5", d, d, 1);
+  }
+  if (a.enable_dilated) {
+    for (int i = 0; i < a.dilated_depth; ++i)
+      m->dil.push_back(P.conv("dilated_conv_stack." + std::to_string(2 * i), d, d, a.dilated_kernel));
+  }
+  m->cls = P.linear("classifier", a.num_classes, d);
+  m->off1 = P.conv("boundary_offset_head.0", d, d, 3);
+  const HostTensor* w2 = P.get("boundary_offset_head.2.weight", {2, d, 1});
+  const HostTensor* b2 = P.get("boundary_offset_head.2.bias", {2});
+  if (w2 && b2) {
+    m->off_w2 = P.upload(w2->data);
+    m->off_b2 = P.upload(b2->data);
+  }
+  return 0;
+}
+
+int32_t wfl_finalize(wfl_model* m) {
+  if (!m) return fail(-1, "wfl_finalize: null model");
+  if (m->finalized) return fail(-1, "wfl_finalize: already finalized");
+  Packer P{m};
+  if (m->a.encoder_type == WFL_ENC_WHISPER) finalize_whisper(m, P);
+  else P.err = "WavLM encoder is not built into this library yet";
+  if (P.err.empty()) finalize_head(m, P);
+  if (!P.err.empty()) return fail(-2, "wfl_finalize: " + P.err);
+  for (auto& kv : m->host)
+    if (!P.used.count(kv.first)) return fail(-2, "wfl_finalize: unexpected key in state_dict: " + kv.first);
+  m->host.clear();
+  m->finalized = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace plan
+namespace {
+
+struct Plan {
+  int B, L, T, P, lead, tail;
+  int T2, P2, lead2;            // whisper stem input rows (mel frames)
+  long R, R2;
+  int d, ffw;
+  // byte offsets
+  long mel, c1, X, Y, ATT, QK, VT, FF, raw, clipmax, logits, logits2, offs2, total;
+};
+
+static Plan make_plan(const wfl_model* m, int B, int L) {
+  const wfl_arch& a = m->a;
+  Plan p{};
+  p.B = B; p.L = L;
+  p.T = a.max_positions;
+  p.P = (int)round_up(p.T + m->halo, 8);
+  p.lead = m->halo;
+  p.tail = 256;
+  p.T2 = 2 * p.T; p.P2 = 2 * p.P; p.lead2 = 8;
+  p.R = p.lead + (long)B * p.P + p.tail;
+  p.R2 = p.lead2 + (long)B * p.P2 + 2 * p.tail;
+  p.d = a.d_model;
+  p.ffw = std::max(a.enc_ffn, a.d_model * std::max(a.conformer_ff_expansion, 1));
+  long off = 0;
+  auto take = [&](long bytes) { long o = off; off = round_up(off + bytes, 256); return o; };
+  p.mel = take(p.R2 * a.n_mels * 2 + 1024);
+  p.c1 = take(p.R2 * p.d * 2);
+  p.X = take(p.R * p.d * 2);
+  p.Y = take(p.R * p.d * 2);
+  p.ATT = take(p.R * p.d * 2);
+  p.QK = take(p.R * 2 * p.d * 2);
+  p.VT = take(((long)B * p.d * p.P + 256) * 2);
+  p.FF = take(p.R * p.ffw * 2);
+  p.raw = take((long)B * p.T2 * a.n_mels * 4);
+  p.clipmax = take((long)B * 4);
+  p.logits = take((long)B * p.T * a.num_classes * 4);
+  p.logits2 = take((long)B * p.T * a.num_classes * 4);
+  p.offs2 = take((long)B * p.T * 2 * 4);
+  p.total = off;
+  return p;
+}
+
+}  // namespace
+
+int32_t wfl_num_frames(const wfl_model* m, int32_t L) {
+  if (!m) return -1;
+  (void)L;
+  return m->a.max_positions;
+}
+
+int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L) {
+  if (!m || B <= 0) return -1;
+  return make_plan(m, B, L).total;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+namespace {
+
+struct Runner {
+  wfl_model* m;
+  Plan p;
+  char* ws;
+  hipStream_t s;
+  int rc = 0;
+
+  bf16_t* buf(long off) const { return (bf16_t*)(ws + off); }
+
+  void gemm(const bf16_t* A, long lda, const Lin& W, int M, int P, int T, void* C, long ldc, long c_lead, int c_pitch,
+            int act = WFL_ACT_NONE, const bf16_t* res = nullptr, long ldres = 0, float alpha = 1.f, int cin = 0,
+            long tap_stride = 0, bool glu = false, bool out_f32 = false, bf16_t* Vt = nullptr, int vt_n0 = 0,
+            const bf16_t* pos = nullptr, long ldpos = 0, const float* clip_bias = nullptr, const int* clip_idx = nullptr,
+            int clip_ld = 0) {
+    if (rc) return;
+    GemmArgs g{};
+    g.A = A; g.lda = lda;
+    g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
+    g.W = W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.n_valid;
+    g.P = P; g.T = T;
+    g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch;
+    g.bias = W.bias; g.clip_bias = clip_bias; g.clip_idx = clip_idx; g.clip_ld = clip_ld;
+    g.res = res; g.ldres = ldres; g.alpha = alpha;
+    g.pos = pos; g.ldpos = ldpos;
+    g.act = act; g.glu = glu ? 1 : 0; g.out_f32 = out_f32 ? 1 : 0;
+    g.Vt = Vt; g.vt_n0 = vt_n0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->prof_on) {
+      if (m->prof_used >= m->prof.ev.size()) {
+        hipEvent_t a_, b_;
+        if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) { rc = fail(-10, "hipEventCreate"); return; }
+        m->prof.ev.push_back({a_, b_});
+      }
+      e0 = m->prof.ev[m->prof_used].first; e1 = m->prof.ev[m->prof_used].second;
+      ++m->prof_used;
+      (void)hipEventRecord(e0, s);
+    }
+    const int r = wfl_launch_gemm(g, s);
+    if (m->prof_on) {
+      (void)hipEventRecord(e1, s);
+      const int key = (act & 7) | (glu ? 8 : 0) | (out_f32 ? 16 : 0) | (Vt ? 32 : 0);
+      m->prof.key.push_back(key);
+      m->prof.launches[key] += 1;
+      m->prof.flops[key] += 2.0 * (double)(M / P) * T * (double)W.n_valid * (double)W.K;
+    }
+    if (r) rc = fail(r, "gemm launch failed (" + std::to_string(r) + ")");
+  }
+
+  void ln(const bf16_t* x, bf16_t* y, const LNp& w) {
+    if (rc) return;
+    const int r = wfl_launch_layernorm(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, s);
+    if (r) rc = fail(r, "layernorm launch failed");
+  }
+
+  void attn(int heads) {
+    if (rc) return;
+    AttnArgs a{};
+    a.QK = buf(p.QK); a.ldqk = 2 * p.d; a.lead = p.lead; a.Vt = buf(p.VT); a.O = buf(p.ATT); a.ldo = p.d;
+    a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = p.d;
+    const int r = wfl_launch_attention(a, s);
+    if (r) rc = fail(r, "attention launch failed (" + std::to_string(r) + "; head_dim " + std::to_string(p.d / heads) + ")");
+  }
+
+  void zero(long off, long ld_elems, long lead, int P, int T, long tail) {
+    if (rc) return;
+    const int r = wfl_launch_zero_halo(buf(off), ld_elems * 2, lead, p.B, P, T, tail, s);
+    if (r) rc = fail(r, "zero_halo launch failed");
+  }
+};
+
+}  // namespace
+
+static int run_logmel(wfl_model* m, const Plan& p, char* ws, const float* wav, long ldw, const int* lens, float* ref_out,
+                      hipStream_t s) {
+  LogmelArgs a{};
+  a.wav = wav; a.ldw = ldw; a.lens = lens; a.L = p.L; a.B = p.B;
+  a.n_frames = p.T2; a.n_samples = p.T2 * 160; a.n_mels = m->a.n_mels;
+  a.Wc = m->Wc; a.Ws = m->Ws; a.mel_lo = m->mel_lo; a.mel_cnt = m->mel_cnt; a.mel_w = m->mel_w; a.mel_maxw = m->mel_maxw;
+  a.raw = (float*)(ws + p.raw); a.clipmax = (unsigned*)(ws + p.clipmax);
+  return wfl_launch_logmel(a, (bf16_t*)(ws + p.mel), m->a.n_mels, p.lead2, p.P2, ref_out, s);
+}
+
+int32_t wfl_logmel(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L, float* out,
+                   void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!m || !m->finalized) return fail(-1, "wfl_logmel: model not finalized");
+  if (m->a.encoder_type != WFL_ENC_WHISPER) return fail(-1, "wfl_logmel: not a Whisper model");
+  if (B <= 0 || L < 0 || ldw < L) return fail(-1, "wfl_logmel: bad shape");
+  const Plan p = make_plan(m, B, L);
+  if (workspace_bytes < p.total) return fail(-1, "wfl_logmel: workspace too small");
+  const int r = run_logmel(m, p, (char*)workspace, wav, ldw, lens, out, (hipStream_t)stream);
+  return r ? fail(r, "logmel launch failed") : 0;
+}
+
+int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,
+                    const int32_t* lang_id, int32_t lang_mode, float threshold, void* workspace, int64_t workspace_bytes,
+                    int32_t* ids, int32_t* argmax, float* maxprob, float* offsets, float* logits, float* hidden,
+                    void* stream) {
+  if (!m || !m->finalized) return fail(-1, "wfl_forward: model not finalized");
+  if (!wav || B <= 0 || L <= 0 || ldw < L) return fail(-1, "wfl_forward: bad input shape");
+  if (!ids || !maxprob || !offsets) return fail(-1, "wfl_forward: ids, maxprob and offsets are required");
+  if (lang_mode == WFL_LANG_IDS && !lang_id) return fail(-1, "wfl_forward: lang_id missing");
+  if (lang_mode == WFL_LANG_AVERAGE && m->a.num_languages <= 0) return fail(-1, "wfl_forward: no languages to average");
+  const wfl_arch& a = m->a;
+  Runner R{m, make_plan(m, B, L), (char*)workspace, (hipStream_t)stream};
+  const Plan& p = R.p;
+  if (workspace_bytes < p.total) return fail(-1, "wfl_forward: workspace too small");
+  const int d = p.d;
+  const long Mrows = (long)B * p.P;
+  bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *VT = R.buf(p.VT), *FF = R.buf(p.FF);
+
+  // halos of every frame-row buffer (cheap; keeps the layout invariant independent of the workspace's history)
+  R.zero(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
+  R.zero(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
+  R.zero(p.X, d, p.lead, p.P, p.T, p.tail);
+  R.zero(p.Y, d, p.lead, p.P, p.T, p.tail);
+  R.zero(p.ATT, d, p.lead, p.P, p.T, p.tail);
+  R.zero(p.QK, 2 * d, p.lead, p.P, p.T, p.tail);
+  R.zero(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
+  if (R.rc) return R.rc;
+
+  // ---- Whisper encoder (HF modeling_whisper.py:618-642)
+  {
+    const int r = run_logmel(m, p, R.ws, wav, ldw, lens, nullptr, R.s);
+    if (r) return fail(r, "logmel launch failed");
+    bf16_t* mel = R.buf(p.mel);
+    bf16_t* c1 = R.buf(p.c1);
+    // conv1 k3 p1: frame t reads mel rows t-1..t+1 = 3*n_mels contiguous channels
+    R.gemm(mel + (long)(p.lead2 - 1) * a.n_mels, a.n_mels, m->conv1, B * p.P2, p.P2, p.T2, c1, d, p.lead2, p.P2, WFL_ACT_GELU);
+    // conv2 k3 s2 p1: frame t reads c1 rows 2t-1..2t+1; pitch(c1) = 2 * pitch(X) makes it one flat GEMM with lda = 2d
+    R.gemm(c1 + (long)(p.lead2 - 1) * d, 2 * d, m->conv2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0,
+           1.f, 0, 0, false, false, nullptr, 0, m->pos, d);
+    for (int i = 0; i < a.enc_layers; ++i) {
+      const EncLayer& L_ = m->enc[i];
+      R.ln(X, Y, L_.ln1);
+      R.gemm(Y + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 2 * d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
+             false, false, VT, 2 * d);
+      R.attn(a.enc_heads);
+      R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
+      R.ln(X, Y, L_.ln2);
+      R.gemm(Y + (long)p.lead * d, d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
+    }
+    R.ln(X, Y, m->enc_ln);       // encoder output in Y
+  }
+  if (R.rc) return R.rc;
+  if (hidden) {
+    const int r = wfl_launch_rows_to_f32(Y, d, p.lead, B, p.P, p.T, d, hidden, R.s);
+    if (r) return fail(r, "rows_to_f32 launch failed");
+  }
+
+  // ---- head (model.py:176-194); with WFL_LANG_AVERAGE it runs once per language on the same encoder output
+  const int n_pass = lang_mode == WFL_LANG_AVERAGE ? a.num_languages : 1;
+  float* lg = logits ? logits : (float*)(R.ws + p.logits);
+  bf16_t* ENC = Y;
+  // the head needs Y as scratch: keep the encoder output in ATT when more than one pass reads it
+  if (n_pass > 1) {
+    HIPCHK(hipMemcpyAsync(R.buf(p.c1), Y, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
+    ENC = R.buf(p.c1);
+  }
+  int* lang_dev = nullptr;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    bf16_t* H;      // current activation
+    bf16_t* S;      // scratch of the same shape
+    if (lang_mode == WFL_LANG_NONE) {
+      H = Y; S = X;
+    } else {
+      const int* idx = lang_id;
+      if (lang_mode == WFL_LANG_AVERAGE) {
+        // clip_idx = pass for every clip: reuse the clipmax slot region (B ints) as a constant index vector
+        lang_dev = (int*)(R.ws + p.clipmax);
+        const int fr = wfl_launch_fill_i32(lang_dev, B, pass, R.s);
+        if (fr) return fail(fr, "fill launch failed");
+        idx = lang_dev;
+      }
+      R.gemm(ENC + (long)p.lead * d, d, m->lang, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
+             false, false, nullptr, 0, nullptr, 0, m->lang_table, idx, d);
+      H = X; S = Y;
+    }
+    for (int i = 0; i < a.n_conformer; ++i) {
+      const ConfLayer& C = m->conf[i];
+      // x = x + 0.5 * FF1(x)
+      R.ln(H, S, C.ff1_ln);
+      R.gemm(S + (long)p.lead * d, d, C.ff1_a, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff1_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
+      // x = LN1(x + MHA(x))
+      R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 2 * d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
+             false, false, VT, 2 * d);
+      R.attn(a.conformer_heads);
+      R.gemm(ATT + (long)p.lead * d, d, C.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+      R.ln(S, H, C.ln1);
+      // x = x + pw2(GELU(BN(conv_k(GLU(pw1(LN2(x)))))))
+      R.ln(H, S, C.ln2);
+      R.gemm(S + (long)p.lead * d, d, C.pw1, (int)Mrows, p.P, p.T, ATT, d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0, true);
+      R.gemm(ATT + (long)(p.lead - a.conformer_kernel / 2) * d, d, C.conv, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU);
+      R.gemm(S + (long)p.lead * d, d, C.pw2, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+      // x = x + 0.5 * FF2(x)
+      R.ln(H, S, C.ff2_ln);
+      R.gemm(S + (long)p.lead * d, d, C.ff2_a, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff2_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
+    }
+    if (a.enable_dilated) {
+      for (int i = 0; i < a.dilated_depth; ++i) {
+        const int dil = 1 << i, pad = dil * (a.dilated_kernel - 1) / 2;
+        R.gemm(H + (long)(p.lead - pad) * d, d, m->dil[i], (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_RELU, nullptr, 0, 1.f,
+               d, (long)dil * d);
+        std::swap(H, S);
+      }
+    }
+    float* lg_pass = (n_pass > 1 && pass > 0) ? (float*)(R.ws + p.logits2) : lg;
+    R.gemm(H + (long)p.lead * d, d, m->cls, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f, 0,
+           0, false, true);
+    R.gemm(H + (long)(p.lead - 1) * d, d, m->off1, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU);
+    if (R.rc) return R.rc;
+    TagArgs t{};
+    t.rows = B * p.T; t.C = a.num_classes; t.threshold = threshold; t.o_id = a.o_id;
+    t.ids = ids; t.argmax = argmax; t.maxprob = maxprob;
+    t.hid = S; t.ldh = d; t.lead = p.lead; t.P = p.P; t.T = p.T; t.d = d; t.w2 = m->off_w2; t.b2 = m->off_b2;
+    if (n_pass == 1) {
+      t.logits = lg; t.ldl = a.num_classes; t.offsets = offsets;
+      const int r = wfl_launch_tag_decide(t, R.s);
+      if (r) return fail(r, "tag_decide launch failed");
+    } else {
+      // offsets of this pass only; logits are decided after the mean
+      t.logits = nullptr;
+      t.offsets = pass == 0 ? offsets : (float*)(R.ws + p.offs2);
+      int r = wfl_launch_tag_decide(t, R.s);
+      if (r) return fail(r, "tag_decide launch failed");
+      const float w = 1.0f / (float)n_pass;
+      const long nl = (long)B * p.T * a.num_classes, no = (long)B * p.T * 2;
+      if (pass == 0) {
+        r = wfl_launch_axpy(lg, lg, nl, w, 1, R.s);
+        if (!r) r = wfl_launch_axpy(offsets, offsets, no, w, 1, R.s);
+      } else {
+        r = wfl_launch_axpy(lg, (float*)(R.ws + p.logits2), nl, w, 0, R.s);
+        if (!r) r = wfl_launch_axpy(offsets, (float*)(R.ws + p.offs2), no, w, 0, R.s);
+      }
+      if (r) return fail(r, "axpy launch failed");
+      if (pass == n_pass - 1) {
+        TagArgs f{};
+        f.logits = lg; f.ldl = a.num_classes; f.rows = B * p.T; f.C = a.num_classes; f.threshold = threshold;
+        f.o_id = a.o_id; f.ids = ids; f.argmax = argmax; f.maxprob = maxprob;
+        r = wfl_launch_tag_decide(f, R.s);
+        if (r) return fail(r, "tag_decide launch failed");
+      }
+    }
+  }
+  return R.rc;
+}
+
+// ------------------------------------------------------------------------------------------------ single-op exports
+int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride, const void* W, int32_t M, int32_t N,
+                    int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead, int32_t c_pitch,
+                    const float* bias, const void* res, int64_t ldres, float alpha, int32_t act, int32_t glu,
+                    int32_t out_f32, void* Vt, int32_t vt_n0, void* stream) {
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.cin = cin > 0 ? cin : K; g.tap_stride = tap_stride;
+  g.W = (const bf16_t*)W; g.M = M; g.N = N; g.K = K; g.n_valid = n_valid; g.P = P; g.T = T;
+  g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch; g.bias = bias;
+  g.res = (const bf16_t*)res; g.ldres = ldres; g.alpha = alpha; g.act = act; g.glu = glu; g.out_f32 = out_f32;
+  g.Vt = (bf16_t*)Vt; g.vt_n0 = vt_n0;
+  const int r = wfl_launch_gemm(g, (hipStream_t)stream);
+  return r ? fail(r, "wfl_op_gemm: invalid arguments or launch failure (" + std::to_string(r) + ")") : 0;
+}
+
+int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* Vt, void* O, int64_t ldo, int32_t B, int32_t T,
+                         int32_t P, int32_t heads, int32_t d, void* stream) {
+  AttnArgs a{};
+  a.QK = (const bf16_t*)QK; a.ldqk = ldqk; a.lead = lead; a.Vt = (const bf16_t*)Vt; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.B = B; a.T = T; a.P = P; a.heads = heads; a.d = d;
+  const int r = wfl_launch_attention(a, (hipStream_t)stream);
+  return r ? fail(r, "wfl_op_attention: invalid arguments, unsupported head_dim or launch failure (" + std::to_string(r) + ")") : 0;
+}
+
+int32_t wfl_op_layernorm(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta, float eps,
+                         int64_t lead, int32_t B, int32_t P, int32_t T, int32_t C, void* stream) {
+  const int r = wfl_launch_layernorm((const bf16_t*)x, ldx, (bf16_t*)y, ldy, gamma, beta, eps, lead, B, P, T, C, (hipStream_t)stream);
+  return r ? fail(r, "wfl_op_layernorm: invalid arguments or launch failure") : 0;
+}
+
+int32_t wfl_op_tag_decide(const float* logits, int64_t ldl, int32_t rows, int32_t C, float threshold, int32_t o_id, int32_t* ids,
+                          int32_t* argmax, float* maxprob, void* stream) {
+  if (!logits || !ids || !maxprob) return fail(-1, "wfl_op_tag_decide: null argument");
+  TagArgs t{};
+  t.logits = logits; t.ldl = ldl; t.rows = rows; t.C = C; t.threshold = threshold; t.o_id = o_id;
+  t.ids = ids; t.argmax = argmax; t.maxprob = maxprob;
+  const int r = wfl_launch_tag_decide(t, (hipStream_t)stream);
+  return r ? fail(r, "wfl_op_tag_decide: launch failure") : 0;
+}
+
+int32_t wfl_gemm_profile_enable(wfl_model* m, int32_t on) {
+  if (!m) return fail(-1, "null model");
+  m->prof_on = on != 0;
+  return 0;
+}
+
+int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys, int64_t* launches, double* total_ms,
+                              double* total_flops, int32_t* n_variants, int32_t reset) {
+  if (!m || !keys || !launches || !total_ms || !total_flops || !n_variants) return fail(-1, "wfl_gemm_profile_read: null argument");
+  double ms[64] = {0};
+  for (size_t i = 0; i < m->prof_used; ++i) {
+    HIPCHK(hipEventSynchronize(m->prof.ev[i].second));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, m->prof.ev[i].first, m->prof.ev[i].second));
+    ms[m->prof.key[i]] += t;
+  }
+  int n = 0;
+  for (int k = 0; k < 64 && n < max_variants; ++k)
+    if (m->prof.launches[k]) {
+      keys[n] = k; launches[n] = m->prof.launches[k]; total_ms[n] = ms[k]; total_flops[n] = m->prof.flops[k];
+      ++n;
+    }
+  *n_variants = n;
+  if (reset) {
+    memset(m->prof.launches, 0, sizeof(m->prof.launches));
+    memset(m->prof.flops, 0, sizeof(m->prof.flops));
+    m->prof.key.clear();
+    m->prof_used = 0;
+  }
+  return 0;
+}

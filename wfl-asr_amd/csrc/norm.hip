@@ -1,0 +1,141 @@
+// LayerNorm over channels of bf16 frame rows (HBM-bound: one read + one write of [B, T, C]), and the halo
+// zeroing that keeps the frame-row layout invariant (common.h).  Replaces nn.LayerNorm calls at HF
+// modeling_whisper.py:391,399,642 and /root/reference/model.py:10,27-28.
+#include "common.h"
+
+// One wave per frame row, 8 channels (16 bytes) per lane per step, statistics in fp32 (mean, then centred
+// variance, as torch does), biased variance, eps inside the rsqrt.
+template <int NCH>   // 16-byte chunks per lane (C <= NCH * 512)
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
+                                                        long ldy, const float* __restrict__ gam,
+                                                        const float* __restrict__ bet, float eps, long lead, int B, int P,
+                                                        int T, int C) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // index over B*T valid rows
+  if (r >= (long)B * T) return;
+  const int b = (int)(r / T), t = (int)(r - (long)b * T);
+  const long row = lead + (long)b * P + t;
+  const bf16_t* xp = x + row * ldx;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < C) {
+      const bf16x8 a = *(const bf16x8*)(xp + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(a[e]); sum += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  bf16_t* yp = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < C) {
+      const f32x4 g0 = *(const f32x4*)(gam + c0), g1 = *(const f32x4*)(gam + c0 + 4);
+      const f32x4 b0 = *(const f32x4*)(bet + c0), b1 = *(const f32x4*)(bet + c0 + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f2bf((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+        o[4 + e] = f2bf((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+      }
+      *(bf16x8*)(yp + c0) = o;
+    }
+  }
+}
+
+int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
+                         long lead, int B, int P, int T, int C, hipStream_t s) {
+  if (C % 8 || ldx % 8 || ldy % 8 || C > 2048) return -1;
+  const long rows = (long)B * T;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (C <= 512)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+  else if (C <= 1024)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Zero every row that is not a valid frame: [0, lead), each clip's [T, P), and `tail_rows` rows behind the last
+// clip.  ld_bytes = bytes per row (multiple of 16).
+__global__ __launch_bounds__(256) void zero_halo_kernel(char* buf, long ld_bytes, long lead, int B, int P, int T,
+                                                        long tail_rows) {
+  const int halo = P - T;
+  const long nrows = lead + (long)B * halo + tail_rows - halo;   // last clip's halo is part of the tail
+  const long chunks_per_row = ld_bytes >> 4;
+  const long total = nrows * chunks_per_row;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long hr = i / chunks_per_row, ch = i - hr * chunks_per_row;
+    long row;
+    if (hr < lead) row = hr;
+    else {
+      const long k = hr - lead;
+      const long b = k / halo;
+      if (b < B - 1) row = lead + b * P + T + (k - b * halo);
+      else row = lead + (long)(B - 1) * P + T + (k - (long)(B - 1) * halo);
+    }
+    *(uint4*)(buf + row * ld_bytes + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+}
+
+int wfl_launch_zero_halo(bf16_t* buf, long ld_bytes, long lead, int B, int P, int T, long tail_rows, hipStream_t s) {
+  if (ld_bytes % 16 || P <= T || tail_rows < P - T) return -1;
+  const long nrows = lead + (long)B * (P - T) + tail_rows - (P - T);
+  const long total = nrows * (ld_bytes >> 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_halo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (char*)buf, ld_bytes, lead, B, P, T, tail_rows);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// bf16 frame rows -> compact fp32 [B][T][C] (parity-test output of the encoder's hidden states)
+__global__ __launch_bounds__(256) void rows_to_f32_kernel(const bf16_t* __restrict__ x, long ldx, long lead, int B, int P, int T,
+                                                          int C, float* __restrict__ out) {
+  const long total = (long)B * T * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    out[i] = bf2f(x[(lead + (long)b * P + t) * ldx + c]);
+  }
+}
+
+int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s) {
+  const long total = (long)B * T * C;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rows_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, C, out);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+__global__ void fill_i32_kernel(int* dst, long n, int value) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = value;
+}
+
+int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, value);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's model object for the inference path.
+
+`BIOPhonemeTagger(config, label_list)` keeps the constructor, attributes and `forward` contract of
+/root/reference/model.py:54-201, but owns no torch modules: weights go straight into the HIP library
+(`load_state_dict` -> wfl_load_tensor/wfl_finalize) and `forward` is one `wfl_forward` call on the
+current HIP stream.  PyTorch is used only for device buffers and the stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .archs import WhisperArch, resolve_encoder_arch
+from .synth import head_config
+
+LANG_NONE, LANG_IDS, LANG_AVERAGE = 0, 1, 2
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class TagBatch:
+    """Decisions for a batch: ids/argmax [B,T] int32, maxprob [B,T], offsets [B,T,2], optional logits/hidden."""
+
+    def __init__(self, ids, argmax, maxprob, offsets, logits=None, hidden=None):
+        self.ids, self.argmax, self.maxprob, self.offsets = ids, argmax, maxprob, offsets
+        self.logits, self.hidden = logits, hidden
+
+
+class BIOPhonemeTagger:
+    def __init__(self, config: dict, label_list):
+        self.config = config
+        self.encoder_type, self.arch = resolve_encoder_arch(config["model"])
+        self.head = head_config(config["model"])
+        self.label_list = list(label_list)
+        self.label2id = {label: i for i, label in enumerate(self.label_list)}
+        self.id2label = {i: label for label, i in self.label2id.items()}
+        if "O" not in self.label2id:
+            raise ValueError('label_list has no "O" tag')
+        self.hidden_size = self.arch.d_model
+        self.num_languages = self.head["num_languages"]
+        self._lib = _lib.load()
+        self._handle = C.c_void_p(0)
+        self._ready = False
+        self._ws = None
+        a = _lib.WflArch()
+        a.abi_version = _lib.ABI_VERSION
+        a.encoder_type = 0 if self.encoder_type == "whisper" else 1
+        a.d_model, a.enc_layers, a.enc_heads, a.enc_ffn = self.arch.d_model, self.arch.layers, self.arch.heads, self.arch.ffn
+        if isinstance(self.arch, WhisperArch):
+            a.n_mels, a.max_positions = self.arch.n_mels, self.arch.max_positions
+            if (self.arch.n_fft, self.arch.hop) != (400, 160):
+                raise ValueError("the log-mel kernel is built for n_fft=400 / hop=160 (every Whisper checkpoint)")
+        else:
+            w = self.arch
+            a.wavlm_n_conv = len(w.conv_dim)
+            for i, (c, k, s) in enumerate(zip(w.conv_dim, w.conv_kernel, w.conv_stride)):
+                a.wavlm_conv_dim[i], a.wavlm_conv_kernel[i], a.wavlm_conv_stride[i] = c, k, s
+            a.wavlm_group_norm = int(w.feat_extract_norm == "group")
+            a.wavlm_conv_bias = int(w.conv_bias)
+            a.wavlm_stable_layer_norm = int(w.stable_layer_norm)
+            a.wavlm_pos_conv_kernel, a.wavlm_pos_conv_groups = w.pos_conv_kernel, w.pos_conv_groups
+            a.wavlm_num_buckets, a.wavlm_max_distance = w.num_buckets, w.max_distance
+            a.wavlm_do_normalize = int(w.do_normalize)
+        h = self.head
+        a.num_classes, a.o_id = len(self.label_list), self.label2id["O"]
+        a.num_languages, a.lang_emb_dim = h["num_languages"], h["lang_emb_dim"]
+        a.enable_bilstm, a.bilstm_layers = int(h["enable_bilstm"]), h["bilstm_num_layer"]
+        a.n_conformer, a.conformer_heads = h["num_conformer_layers"], h["conformer_heads"]
+        a.conformer_ff_expansion, a.conformer_kernel = h["conformer_ff_expansion"], h["conformer_kernel_size"]
+        a.enable_dilated, a.dilated_depth, a.dilated_kernel = int(h["enable_dilated_conv"]), h["dilated_conv_depth"], h["dilated_conv_kernel"]
+        _lib.check(self._lib.wfl_create(C.byref(a), C.byref(self._handle)), "wfl_create")
+
+    # ---- nn.Module-shaped conveniences the reference's infer.py uses (infer.py:205-208)
+    def load_state_dict(self, state_dict, strict: bool = True):
+        if not strict:
+            raise ValueError("only strict loading is supported (as at /root/reference/infer.py:207)")
+        for name, t in state_dict.items():
+            if isinstance(t, torch.Tensor):
+                t = t.detach().cpu()
+                arr = t.to(torch.float32).numpy() if t.dtype != torch.float32 else t.numpy()
+            else:
+                arr = np.asarray(t)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(self._lib.wfl_load_tensor(self._handle, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim),
+                       f"wfl_load_tensor({name})")
+        _lib.check(self._lib.wfl_finalize(self._handle), "load_state_dict")
+        self._ready = True
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.WflError("this build runs on MI355X only (device must be cuda[:N]); there is no CPU path")
+        return self
+
+    def eval(self):
+        return self
+
+    def num_frames(self, L: int) -> int:
+        return int(self._lib.wfl_num_frames(self._handle, int(L)))
+
+    def _workspace(self, B: int, L: int, device):
+        need = int(self._lib.wfl_workspace_bytes(self._handle, B, L))
+        if need <= 0:
+            raise _lib.WflError("wfl_workspace_bytes failed")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    @torch.no_grad()
+    def label(self, input_values: torch.Tensor, lang_id=None, threshold: float = 0.0, lens=None,
+              average_languages: bool = False, want_logits: bool = False, want_hidden: bool = False) -> TagBatch:
+        """The batched fast path: [B, L] fp32 16 kHz clips -> per-frame decisions (all on the GPU)."""
+        if not self._ready:
+            raise _lib.WflError("load_state_dict() has not been called")
+        if not input_values.is_cuda:
+            raise _lib.WflError("input_values must be a CUDA (ROCm) tensor; there is no CPU path")
+        x = input_values.to(torch.float32).contiguous()
+        if x.dim() != 2:
+            raise ValueError("input_values must be [B, L]")
+        B, L = x.shape
+        dev = x.device
+        T = self.num_frames(L)
+        Cn = len(self.label_list)
+        ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+        arg = torch.empty(B, T, dtype=torch.int32, device=dev)
+        maxp = torch.empty(B, T, dtype=torch.float32, device=dev)
+        offs = torch.empty(B, T, 2, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, T, Cn, dtype=torch.float32, device=dev) if want_logits else None
+        hidden = torch.empty(B, T, self.hidden_size, dtype=torch.float32, device=dev) if want_hidden else None
+        lang_t = None
+        if average_languages:
+            mode = LANG_AVERAGE
+        elif lang_id is None:
+            mode = LANG_NONE
+        else:
+            mode = LANG_IDS
+            lang_t = torch.as_tensor(lang_id, device=dev).to(torch.int32).contiguous()
+            if lang_t.numel() != B:
+                raise ValueError("lang_id must have one entry per clip")
+            if int(lang_t.max()) >= self.num_languages or int(lang_t.min()) < 0:
+                raise ValueError(f"Language ID out of range (num_languages={self.num_languages})")
+        lens_t = torch.as_tensor(lens, device=dev).to(torch.int32).contiguous() if lens is not None else None
+        ws = self._workspace(B, L, dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = self._lib.wfl_forward(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(lang_t), mode,
+                                       float(threshold), _ptr(ws), ws.numel(), _ptr(ids), _ptr(arg), _ptr(maxp),
+                                       _ptr(offs), _ptr(logits), _ptr(hidden), C.c_void_p(stream))
+        _lib.check(rc, "wfl_forward")
+        return TagBatch(ids, arg, maxp, offs, logits, hidden)
+
+    def forward(self, input_values, lang_id=None, max_label_len=None):
+        """Reference contract (model.py:148-194): returns (logits [B,T,C] f32, offsets [B,T,2] f32)."""
+        if max_label_len is not None:
+            raise NotImplementedError("max_label_len (training-time pad/truncate, model.py:166-174) is out of scope")
+        out = self.label(input_values, lang_id, want_logits=True)
+        return out.logits, out.offsets
+
+    __call__ = forward
+
+    def log_mel(self, input_values: torch.Tensor, lens=None) -> torch.Tensor:
+        """[B, L] -> [B, n_mels, frames] fp32, the WhisperFeatureExtractor output (model.py:153-154)."""
+        x = input_values.to(torch.float32).contiguous()
+        B, L = x.shape
+        out = torch.empty(B, self.arch.n_mels, 2 * self.arch.max_positions, dtype=torch.float32, device=x.device)
+        lens_t = torch.as_tensor(lens, device=x.device).to(torch.int32).contiguous() if lens is not None else None
+        ws = self._workspace(B, L, x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = self._lib.wfl_logmel(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(out), _ptr(ws),
+                                      ws.numel(), C.c_void_p(stream))
+        _lib.check(rc, "wfl_logmel")
+        return out
+
+    def decode_predictions(self, logits):
+        return torch.argmax(logits, dim=-1)
+
+    def id_to_label(self, ids):
+        return [[self.id2label[int(i)] for i in seq] for seq in ids]
+
+    # ---- GEMM timing hook (bench.py roofline)
+    def gemm_profile(self, on: bool):
+        _lib.check(self._lib.wfl_gemm_profile_enable(self._handle, int(on)), "wfl_gemm_profile_enable")
+
+    def gemm_profile_read(self, reset=True):
+        n = 64
+        keys = (C.c_int32 * n)()
+        launches = (C.c_int64 * n)()
+        ms = (C.c_double * n)()
+        fl = (C.c_double * n)()
+        cnt = C.c_int32(0)
+        _lib.check(self._lib.wfl_gemm_profile_read(self._handle, n, keys, launches, ms, fl, C.byref(cnt), int(reset)),
+                   "wfl_gemm_profile_read")
+        return [dict(key=int(keys[i]), launches=int(launches[i]), ms=float(ms[i]), flops=float(fl[i])) for i in range(cnt.value)]
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self._lib.wfl_destroy(self._handle)
+                self._handle = C.c_void_p(0)
+        except Exception:
+            pass
