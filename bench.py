@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds labeled per second per node (BASELINE.json metric).
+
+One process per GPU (`--gpus N`; for N > 1 launched by torch.distributed.run, RCCL backend).  A step is one pass of
+the labeling hot path over one batch of synthetic 30 s clips that is already resident in HBM:
+  log-mel -> Whisper-base encoder -> lang_proj -> 2 Conformer blocks -> classifier + offset head -> tag decision
+  -> (N > 1: RCCL gather of the tag tensors to rank 0) -> tags copied to pinned host memory on the owning rank.
+Workload = BASELINE.json configs[1]: Whisper-base + 2 Conformer blocks, bf16, 16 x 30 s clips per GPU (weak scaling:
+the clips are independent, ranks share nothing but the final gather).
+
+Besides the contract fields the JSON line carries
+  roofline      the dominant kernel (bf16 MFMA GEMM family): algorithmic FLOPs / HIP-event time per launch, measured
+                on the launch stream inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the oracle (pure-torch fp32 CPU restatement of the reference forward, kind "port") timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+CLIP_SECONDS = 30.0
+SR = 16000
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="30 s clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2, help="clips per CPU-baseline call")
+    ap.add_argument("--cpu-calls", type=int, default=3)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the HIP-event pass that times every GEMM launch")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one captured HIP graph per step")
+    ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (Whisper configs only)")
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: the cgroup CPU quota when there is one (the GPU box hands a 1-GPU job a
+    share of the host, not all 256 hardware threads), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("WFL_CPU_BASELINE_THREADS")
+    if env:
+        n = int(env)
+    return n
+
+
+def cpu_baseline(cfg, labels, sd_np, clips, calls):
+    """The oracle forward on host cores.  Only this leg (and tests / smoke) may touch oracle/."""
+    from oracle import wfl_oracle as O
+    from wfl_asr_amd import synth
+    from wfl_asr_amd.archs import resolve_encoder_arch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    enc, arch = resolve_encoder_arch(cfg["model"])
+    sd = O.to_torch_state_dict(sd_np)
+    hc = synth.head_config(cfg["model"])
+    wav = torch.from_numpy(synth.make_batch(90000, clips, int(CLIP_SECONDS * SR), seed=1))
+    lang = torch.arange(clips) % cfg["model"]["num_languages"]
+    o_id = labels.index("O")
+
+    def call():
+        lg, of = O.forward(wav, lang, sd, enc, arch, hc)
+        return O.tags_from_logits(lg, o_id, 0.5)
+
+    call()                                   # warm-up
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {
+        "value": clips * CLIP_SECONDS / med, "unit": "audio-s/s", "cores": cores, "kind": "port",
+        "sample": f"{calls} calls x {clips} clips x 30 s (same config, fp32, torch CPU, batch {clips}); median call {med:.3f} s",
+        "torch_threads": torch.get_num_threads(),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wfl_asr_amd import synth
+    from wfl_asr_amd.tagger import BIOPhonemeTagger
+    from wfl_asr_amd.dist import gather_tags
+
+    cfg = synth.baseline_config(args.config_index)
+    labels = synth.make_labels(70)
+    sd_np = synth.make_state_dict(cfg, len(labels), seed=1)
+    model = BIOPhonemeTagger(cfg, labels)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model.to(dev).eval()
+
+    B, L = args.batch, int(CLIP_SECONDS * SR)
+    wav = torch.from_numpy(synth.make_batch(10000 + rank * B, B, L, seed=1)).to(dev)     # resident in HBM
+    lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
+    T = model.num_frames(L)
+    n_host = B * (world if rank == 0 else 1)
+    host_ids = torch.empty(n_host, T, dtype=torch.int32).pin_memory()
+    host_maxp = torch.empty(n_host, T, dtype=torch.float32).pin_memory()
+    host_offs = torch.empty(n_host, T, 2, dtype=torch.float32).pin_memory()
+
+    use_graph = not args.no_graph
+
+    def step(graph=use_graph):
+        out = model.label(wav, lang, threshold=0.5, graph=graph)
+        if world > 1:
+            ids, maxp, offs = gather_tags(out.ids, out.maxprob, out.offsets, dst=0)
+            if rank != 0:
+                return
+        else:
+            ids, maxp, offs = out.ids, out.maxprob, out.offsets
+        host_ids.copy_(ids, non_blocking=True)
+        host_maxp.copy_(maxp, non_blocking=True)
+        host_offs.copy_(offs, non_blocking=True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # Roofline pass: the same K steps again, launched eagerly with a HIP-event pair around every GEMM launch on the
+    # launch stream (events cannot live inside a replayed graph; the kernels and their inputs are identical).
+    use_events = not args.no_kernel_events
+    prof = []
+    if use_events:
+        step(graph=False)
+        fence()
+        model.gemm_profile(True)
+        model.gemm_profile_read(reset=True)
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            step(graph=False)
+        fence()
+        eager_ms = 1e3 * (time.perf_counter() - te) / args.steps
+        prof = model.gemm_profile_read(reset=True)
+        model.gemm_profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        audio_s = world * B * CLIP_SECONDS * args.steps
+        roof = None
+        if prof:
+            names = {0: "none", 1: "gelu", 2: "relu", 3: "sigmoid"}
+            tot_ms = sum(p["ms"] for p in prof)
+            tot_fl = sum(p["flops"] for p in prof)
+            tot_n = sum(p["launches"] for p in prof)
+            top = max(prof, key=lambda p: p["ms"])
+            roof = {
+                "bound": "mfma", "kernel": "gemm_bf16_kernel<ACT,GLU,OUTF32,VT> (all instantiations)",
+                "timing": "HIP events around every GEMM launch, same %d steps re-run eagerly after the timed region "
+                          "(%.3f ms/step with events)" % (args.steps, eager_ms),
+                "achieved": tot_fl / tot_ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": tot_n / args.steps, "avg_launch_us": 1e3 * tot_ms / tot_n,
+                "gflop_per_launch": tot_fl / tot_n / 1e9, "gemm_ms_per_step": tot_ms / args.steps,
+                "variants": [
+                    {"act": names[p["key"] & 7], "glu": bool(p["key"] & 8), "out_f32": bool(p["key"] & 16),
+                     "vt": bool(p["key"] & 32), "launches": p["launches"], "avg_us": 1e3 * p["ms"] / p["launches"],
+                     "tflops": p["flops"] / p["ms"] / 1e9}
+                    for p in sorted(prof, key=lambda p: -p["ms"])],
+                "top_variant": {"act": names[top["key"] & 7], "avg_us": 1e3 * top["ms"] / top["launches"],
+                                "tflops": top["flops"] / top["ms"] / 1e9},
+            }
+        result = {
+            "metric": "audio_seconds_labeled_per_sec_per_node", "value": audio_s / elapsed, "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %s + %d Conformer blocks, %d x 30 s clips per GPU" % (
+                args.config_index, cfg["model"]["whisper_model"], cfg["model"]["num_conformer_layers"], B),
+                "clips_per_gpu": B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": T, "tags": len(labels),
+                "parallelism": f"clip-sharded dp{world}", "launch": "hip graph replay" if use_graph else "eager"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, labels, sd_np, args.cpu_clips, args.cpu_calls)
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the multi-rank path of the labeler (sharding plan + the single tag gather)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from wfl_asr_amd import dist as wd
+
+
+def test_shard_items_balanced_and_deterministic():
+    costs = [480000, 10, 480000, 300000, 300000, 5, 160000, 160000, 160000]
+    plan = wd.shard_items(costs, 4)
+    assert sorted(i for p in plan for i in p) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in p) for p in plan]
+    assert max(loads) - min(loads) <= max(costs)
+    assert plan == wd.shard_items(costs, 4)
+    assert wd.shard_items([], 3) == [[], [], []]
+    assert wd.shard_items([7], 2) == [[0], []]
+
+
+def test_pack_roundtrip_bit_exact():
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 141, (3, 50), generator=g, dtype=torch.int32)
+    mp_ = torch.rand(3, 50, generator=g)
+    off = torch.rand(3, 50, 2, generator=g)
+    mp_[0, 0] = float("nan"); off[1, 2, 1] = -0.0
+    a, b, c = wd.unpack_tags(wd.pack_tags(ids, mp_, off))
+    assert torch.equal(a, ids)
+    assert torch.equal(b.view(torch.int32), mp_.view(torch.int32)) and torch.equal(c.view(torch.int32), off.view(torch.int32))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, counts, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T = 37
+        n = counts[rank]
+        g = torch.Generator().manual_seed(100 + rank)
+        ids = torch.randint(0, 141, (n, T), generator=g, dtype=torch.int32)
+        mp_ = torch.rand(n, T, generator=g)
+        off = torch.rand(n, T, 2, generator=g)
+        a, b, c = wd.gather_tags(ids, mp_, off, dst=0, counts=counts)
+        if rank == 0:
+            q.put((a, b, c))
+        else:
+            assert a is ids and b is mp_ and c is off
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [[3, 3], [4, 1], [2, 0]])
+def test_gather_tags_world2_gloo(counts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, b, c = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    T = 37
+    exp_ids, exp_mp, exp_off = [], [], []
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        exp_ids.append(torch.randint(0, 141, (counts[r], T), generator=g, dtype=torch.int32))
+        exp_mp.append(torch.rand(counts[r], T, generator=g))
+        exp_off.append(torch.rand(counts[r], T, 2, generator=g))
+    assert torch.equal(a, torch.cat(exp_ids)) and torch.equal(b, torch.cat(exp_mp)) and torch.equal(c, torch.cat(exp_off))

@@ -51,7 +51,7 @@ struct GemmArgs {
   int act;
   int glu;                  // weights row-interleaved in groups of 16 (a | gate); N_out = N / 2
   int out_f32;
-  bf16_t* Vt;               // columns >= vt_n0 are written transposed: Vt[(b * (N - vt_n0) + n - vt_n0) * P + t]
+  bf16_t* Vt;               // columns >= vt_n0 are written transposed: Vt[(b * (n_valid - vt_n0) + n - vt_n0) * P + t]
   int vt_n0;                // (multiple of 128); frames t in [T, P) of Vt are written as zero
 };
 

@@ -18,7 +18,7 @@
 #define BN 128
 #define BK 64
 #define STAGE_BYTES (2 * BM * BK * 2)   // A tile + W tile
-#define LDS_BYTES (2 * STAGE_BYTES)
+#define LDS_BYTES (128 * 132 * 4)          // two operand stages (64 KiB) < the fp32 epilogue tile (66 KiB)
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -119,91 +119,135 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   }
 
   // ------------------------------------------------------------------ epilogue
+  // The accumulators leave through LDS so that HBM sees whole rows: every lane owns 4 channels x 1 frame per MFMA
+  // tile, which as direct stores is 16 scattered 8-byte stores per lane (store-issue bound, 32-byte segments).
+  // Stage 1 applies bias / per-clip bias / activation / GLU in fp32 and parks the 128x128 tile in LDS
+  // (row pitch 132 floats: the 8 lanes of a ds_write_b128 group hit 8 distinct 4-bank slots); stage 2 re-reads it
+  // row-wise, adds the positional table and the residual with 16-byte loads and writes 16 bytes per lane.
+  constexpr int NC = GLU ? 64 : 128;          // staged columns
+  constexpr int EP = NC + 4;                  // pitch in floats
+  float* stg = (float*)smem;
+  __syncthreads();                            // all waves are done with the operand stages
   if (VT && swap_roles) {
-    // acc[i][j][e]: frame m = m0+wm+16i+4*(lane>>4)+e, channel n = n0+wn+16j+(lane&15); 4 consecutive frames/lane
-    const int nv = p.N - p.vt_n0;
+    // acc[i][j][e]: frame m = wm+16i+4g+e, channel n = wn+16j+c  ->  staged transposed [n][m]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm + i * 16 + (lane >> 4) * 4;
-      if (m >= p.M) continue;
-      const int b = m / p.P, t = m - b * p.P;
+    for (int j = 0; j < 4; ++j) {
+      const int nl = wn + j * 16 + (lane & 15);
+      const float bv = p.bias ? p.bias[n0 + nl] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn + j * 16 + (lane & 15);
-        if (n >= p.n_valid) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-        bf16x4 o;
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = acc[i][j];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf((t + e < p.T) ? acc[i][j][e] + bv : 0.f);
-        *(bf16x4*)(p.Vt + ((long)b * nv + (n - p.vt_n0)) * p.P + t) = o;
+        for (int e = 0; e < 4; ++e) v[e] += bv;
+        *(f32x4*)(stg + nl * EP + wm + i * 16 + (lane >> 4) * 4) = v;
       }
+    }
+    __syncthreads();
+    const int nv = p.n_valid - p.vt_n0;       // channels in the transposed block (N is padded)
+    const int cidx = tid & 15;
+    const int m = m0 + cidx * 8;
+    const int b = m / p.P, t = m - b * p.P;   // 8 frames from a multiple of 8 never straddle clips (P % 8 == 0)
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int r = pass * 16 + (tid >> 4);
+      const int n = n0 + r;
+      if (n >= p.n_valid || m >= p.M) continue;
+      const f32x4 v0 = *(const f32x4*)(stg + r * EP + cidx * 8);
+      const f32x4 v1 = *(const f32x4*)(stg + r * EP + cidx * 8 + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f2bf(t + e < p.T ? v0[e] : 0.f);
+        o[4 + e] = f2bf(t + 4 + e < p.T ? v1[e] : 0.f);
+      }
+      *(bf16x8*)(p.Vt + ((long)b * nv + (n - p.vt_n0)) * p.P + t) = o;
     }
     return;
   }
 
-  // acc[i][j][e]: frame m = m0+wm+16i+(lane&15), channel n = n0+wn+16j+4*(lane>>4)+e
+  // stage 1: acc[i][j][e] is frame m = wm+16i+c, channel n = wn+16j+4g+e
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    const int b = m / p.P, t = m - b * p.P;
-    if (t >= p.T) continue;
-    const long orow = p.c_lead + (long)b * p.c_pitch + t;
-    const float* cb = p.clip_bias ? p.clip_bias + (long)p.clip_idx[b] * p.clip_ld : nullptr;
+    const int ml = wm + i * 16 + (lane & 15);
+    const float* cb = nullptr;
+    if (p.clip_bias) {
+      int m = m0 + ml;
+      m = m < p.M ? m : p.M - 1;
+      cb = p.clip_bias + (long)p.clip_idx[m / p.P] * p.clip_ld;
+    }
     if (GLU) {
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         const int n = n0 + wn + jp * 32 + (lane >> 4) * 4;        // 'a' rows; gates at n + 16
-        const int oc = (n0 + wn) / 2 + jp * 16 + (lane >> 4) * 4;  // output channel
-        if (n >= p.n_valid) continue;
         f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) { ba = *(const f32x4*)(p.bias + n); bg = *(const f32x4*)(p.bias + n + 16); }
-        bf16x4 o;
+        f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = acc[i][2 * jp][e] + ba[e];
-          const float g = acc[i][2 * jp + 1][e] + bg[e];
-          o[e] = f2bf(a * sigmoidf_(g));
-        }
-        *(bf16x4*)((bf16_t*)p.C + orow * p.ldc + oc) = o;
+        for (int e = 0; e < 4; ++e) v[e] = (acc[i][2 * jp][e] + ba[e]) * sigmoidf_(acc[i][2 * jp + 1][e] + bg[e]);
+        *(f32x4*)(stg + ml * EP + wn / 2 + jp * 16 + (lane >> 4) * 4) = v;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn + j * 16 + (lane >> 4) * 4;
-        if (n >= p.n_valid) continue;
+        const int nl = wn + j * 16 + (lane >> 4) * 4;
         f32x4 v = acc[i][j];
-        if (p.bias) { const f32x4 bb = *(const f32x4*)(p.bias + n); v += bb; }
-        if (cb) { const f32x4 bb = *(const f32x4*)(cb + n); v += bb; }
+        if (p.bias) { const f32x4 bb = *(const f32x4*)(p.bias + n0 + nl); v += bb; }
+        if (cb) { const f32x4 bb = *(const f32x4*)(cb + n0 + nl); v += bb; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
-        if (p.pos) {
-          const bf16x4 pp = *(const bf16x4*)(p.pos + (long)t * p.ldpos + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(pp[e]);
-        }
-        if (p.res) {
-          const bf16x4 rr = *(const bf16x4*)(p.res + orow * p.ldres + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = bf2f(rr[e]) + p.alpha * v[e];
-        }
-        if (OUTF32) {
-          float* o = (float*)p.C + orow * p.ldc + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.n_valid) o[e] = v[e];
-        } else if (n + 4 <= p.n_valid) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-          *(bf16x4*)((bf16_t*)p.C + orow * p.ldc + n) = o;
-        } else {
-          bf16_t* o = (bf16_t*)p.C + orow * p.ldc + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.n_valid) o[e] = f2bf(v[e]);
-        }
+        *(f32x4*)(stg + ml * EP + nl) = v;
       }
+    }
+  }
+  __syncthreads();
+
+  // stage 2: thread -> 8 consecutive channels of one frame per pass
+  constexpr int CP = NC / 8;                  // 8-channel chunks per row
+  constexpr int RPP = 256 / CP;               // rows per pass
+  const int cidx = tid % CP;
+  const int nb = (GLU ? n0 / 2 : n0) + cidx * 8;
+  const int nvalid = GLU ? p.n_valid / 2 : p.n_valid;
+  if (nb >= nvalid) return;
+#pragma unroll
+  for (int pass = 0; pass < 128 / RPP; ++pass) {
+    const int r = pass * RPP + tid / CP;
+    const int m = m0 + r;
+    if (m >= p.M) continue;
+    const int b = m / p.P, t = m - b * p.P;
+    if (t >= p.T) continue;
+    const long orow = p.c_lead + (long)b * p.c_pitch + t;
+    float v[8];
+    {
+      const f32x4 v0 = *(const f32x4*)(stg + r * EP + cidx * 8);
+      const f32x4 v1 = *(const f32x4*)(stg + r * EP + cidx * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+    }
+    if (p.pos) {
+      const bf16x8 pp = *(const bf16x8*)(p.pos + (long)t * p.ldpos + nb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[e]);
+    }
+    if (p.res) {
+      const bf16x8 rr = *(const bf16x8*)(p.res + orow * p.ldres + nb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[e]) + p.alpha * v[e];
+    }
+    if (OUTF32) {
+      float* o = (float*)p.C + orow * p.ldc + nb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (nb + e < nvalid) o[e] = v[e];
+    } else if (nb + 8 <= nvalid) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      *(bf16x8*)((bf16_t*)p.C + orow * p.ldc + nb) = o;
+    } else {
+      bf16_t* o = (bf16_t*)p.C + orow * p.ldc + nb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (nb + e < nvalid) o[e] = f2bf(v[e]);
     }
   }
 }
@@ -222,8 +266,8 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
 }
 
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
-  if (a.M <= 0 || a.N <= 0 || a.N % BN || a.K <= 0 || a.K % BK || a.cin <= 0 || a.cin % BK || a.P <= 0 || a.P % 4 ||
-      a.ldc % 4 || (a.res && a.ldres % 4) || (a.pos && a.ldpos % 4) || (a.Vt && a.vt_n0 % BN))
+  if (a.M <= 0 || a.N <= 0 || a.N % BN || a.K <= 0 || a.K % BK || a.cin <= 0 || a.cin % BK || a.P <= 0 || a.P % 8 ||
+      (!a.out_f32 && a.ldc % 8) || (a.res && a.ldres % 8) || (a.pos && a.ldpos % 8) || (a.Vt && a.vt_n0 % BN))
     return -1;
   if (a.glu) {
     if (a.out_f32 || a.act != WFL_ACT_NONE || a.Vt) return -1;

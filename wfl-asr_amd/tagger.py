@@ -47,6 +47,7 @@ class BIOPhonemeTagger:
         self._handle = C.c_void_p(0)
         self._ready = False
         self._ws = None
+        self._graphs = {}
         a = _lib.WflArch()
         a.abi_version = _lib.ABI_VERSION
         a.encoder_type = 0 if self.encoder_type == "whisper" else 1
@@ -110,31 +111,65 @@ class BIOPhonemeTagger:
         if need <= 0:
             raise _lib.WflError("wfl_workspace_bytes failed")
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            if self._graphs:
+                raise _lib.WflError("workspace must not grow while captured graphs hold its address; "
+                                    "label the largest batch first or create a new tagger")
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
+    def _check_lang(self, lang_id, B):
+        """Range check on the host copy of lang_id (no device sync); returns an int32 CPU/CUDA tensor."""
+        if isinstance(lang_id, torch.Tensor) and lang_id.is_cuda:
+            t = lang_id.to(torch.int32)
+        else:
+            t = torch.as_tensor(lang_id).to(torch.int32).reshape(-1)
+            if t.numel() and (int(t.max()) >= self.num_languages or int(t.min()) < 0):
+                raise ValueError(f"Language ID out of range (num_languages={self.num_languages})")
+        if t.numel() != B:
+            raise ValueError("lang_id must have one entry per clip")
+        return t
+
+    def _launch(self, x, lens_t, lang_t, mode, threshold, out: "TagBatch"):
+        B, L = x.shape
+        ws = self._workspace(B, L, x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = self._lib.wfl_forward(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(lang_t), mode,
+                                       float(threshold), _ptr(ws), ws.numel(), _ptr(out.ids), _ptr(out.argmax),
+                                       _ptr(out.maxprob), _ptr(out.offsets), _ptr(out.logits), _ptr(out.hidden),
+                                       C.c_void_p(stream))
+        _lib.check(rc, "wfl_forward")
+
+    def _alloc_out(self, B, T, dev, want_logits, want_hidden) -> "TagBatch":
+        Cn = len(self.label_list)
+        return TagBatch(
+            torch.empty(B, T, dtype=torch.int32, device=dev), torch.empty(B, T, dtype=torch.int32, device=dev),
+            torch.empty(B, T, dtype=torch.float32, device=dev), torch.empty(B, T, 2, dtype=torch.float32, device=dev),
+            torch.empty(B, T, Cn, dtype=torch.float32, device=dev) if want_logits else None,
+            torch.empty(B, T, self.hidden_size, dtype=torch.float32, device=dev) if want_hidden else None)
+
     @torch.no_grad()
     def label(self, input_values: torch.Tensor, lang_id=None, threshold: float = 0.0, lens=None,
-              average_languages: bool = False, want_logits: bool = False, want_hidden: bool = False) -> TagBatch:
-        """The batched fast path: [B, L] fp32 16 kHz clips -> per-frame decisions (all on the GPU)."""
+              average_languages: bool = False, want_logits: bool = False, want_hidden: bool = False,
+              graph: bool = False) -> TagBatch:
+        """The batched fast path: [B, L] fp32 16 kHz clips -> per-frame decisions (all on the GPU).
+
+        graph=True replays the whole forward (about 100 kernel launches) as one captured HIP graph per
+        (B, L, mode) signature; inputs are copied into static buffers and the returned tensors are the graph's
+        static outputs (consume them before the next call with the same signature)."""
         if not self._ready:
             raise _lib.WflError("load_state_dict() has not been called")
         if not input_values.is_cuda:
             raise _lib.WflError("input_values must be a CUDA (ROCm) tensor; there is no CPU path")
-        x = input_values.to(torch.float32).contiguous()
-        if x.dim() != 2:
+        if input_values.dim() != 2:
             raise ValueError("input_values must be [B, L]")
+        x = input_values.to(torch.float32)
+        if x.stride(1) != 1:
+            x = x.contiguous()
         B, L = x.shape
         dev = x.device
         T = self.num_frames(L)
-        Cn = len(self.label_list)
-        ids = torch.empty(B, T, dtype=torch.int32, device=dev)
-        arg = torch.empty(B, T, dtype=torch.int32, device=dev)
-        maxp = torch.empty(B, T, dtype=torch.float32, device=dev)
-        offs = torch.empty(B, T, 2, dtype=torch.float32, device=dev)
-        logits = torch.empty(B, T, Cn, dtype=torch.float32, device=dev) if want_logits else None
-        hidden = torch.empty(B, T, self.hidden_size, dtype=torch.float32, device=dev) if want_hidden else None
         lang_t = None
         if average_languages:
             mode = LANG_AVERAGE
@@ -142,20 +177,46 @@ class BIOPhonemeTagger:
             mode = LANG_NONE
         else:
             mode = LANG_IDS
-            lang_t = torch.as_tensor(lang_id, device=dev).to(torch.int32).contiguous()
-            if lang_t.numel() != B:
-                raise ValueError("lang_id must have one entry per clip")
-            if int(lang_t.max()) >= self.num_languages or int(lang_t.min()) < 0:
-                raise ValueError(f"Language ID out of range (num_languages={self.num_languages})")
-        lens_t = torch.as_tensor(lens, device=dev).to(torch.int32).contiguous() if lens is not None else None
-        ws = self._workspace(B, L, dev)
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = self._lib.wfl_forward(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(lang_t), mode,
-                                       float(threshold), _ptr(ws), ws.numel(), _ptr(ids), _ptr(arg), _ptr(maxp),
-                                       _ptr(offs), _ptr(logits), _ptr(hidden), C.c_void_p(stream))
-        _lib.check(rc, "wfl_forward")
-        return TagBatch(ids, arg, maxp, offs, logits, hidden)
+            lang_t = self._check_lang(lang_id, B)
+        lens_t = torch.as_tensor(lens).to(torch.int32).reshape(-1) if lens is not None else None
+        if lens_t is not None and lens_t.numel() != B:
+            raise ValueError("lens must have one entry per clip")
+        if not graph:
+            lang_d = lang_t.to(dev).contiguous() if lang_t is not None else None
+            lens_d = lens_t.to(dev).contiguous() if lens_t is not None else None
+            out = self._alloc_out(B, T, dev, want_logits, want_hidden)
+            self._launch(x, lens_d, lang_d, mode, threshold, out)
+            return out
+        key = (B, L, mode, float(threshold), want_logits, want_hidden, lens_t is not None, dev.index)
+        g = self._graphs.get(key)
+        if g is None:
+            st = dict(
+                x=torch.empty(B, L, dtype=torch.float32, device=dev),
+                lang=torch.zeros(B, dtype=torch.int32, device=dev) if lang_t is not None else None,
+                lens=torch.zeros(B, dtype=torch.int32, device=dev) if lens_t is not None else None,
+                out=self._alloc_out(B, T, dev, want_logits, want_hidden))
+            st["x"].copy_(x)
+            if lang_t is not None:
+                st["lang"].copy_(lang_t)
+            if lens_t is not None:
+                st["lens"].copy_(lens_t)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):           # warm-up outside capture (function attributes, workspace)
+                self._launch(st["x"], st["lens"], st["lang"], mode, threshold, st["out"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                self._launch(st["x"], st["lens"], st["lang"], mode, threshold, st["out"])
+            st["graph"] = cg
+            self._graphs[key] = g = st
+        g["x"].copy_(x, non_blocking=True)
+        if lang_t is not None:
+            g["lang"].copy_(lang_t, non_blocking=True)
+        if lens_t is not None:
+            g["lens"].copy_(lens_t, non_blocking=True)
+        g["graph"].replay()
+        return g["out"]
 
     def forward(self, input_values, lang_id=None, max_label_len=None):
         """Reference contract (model.py:148-194): returns (logits [B,T,C] f32, offsets [B,T,2] f32)."""
@@ -203,6 +264,7 @@ class BIOPhonemeTagger:
 
     def __del__(self):
         try:
+            self._graphs.clear()
             if self._handle:
                 self._lib.wfl_destroy(self._handle)
                 self._handle = C.c_void_p(0)
