@@ -12,7 +12,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libwfl_asr_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's register file is unified).  With the default AGPR
+# form hipcc (ROCm 7.2) rotates the 64 accumulator registers of the software-pipelined GEMM loop through
+# v_accvgpr_mov every iteration (~40 extra instructions per K tile).
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc() -> str:

@@ -53,6 +53,9 @@ struct GemmArgs {
   int out_f32;
   bf16_t* Vt;               // columns >= vt_n0 are written transposed: Vt[(b * (n_valid - vt_n0) + n - vt_n0) * P + t]
   int vt_n0;                // (multiple of 128); frames t in [T, P) of Vt are written as zero
+#ifdef WFL_GEMM_STAMPS
+  unsigned long long* stamps;   // diagnostic build: [blocks][8]
+#endif
 };
 
 struct AttnArgs {
@@ -67,7 +70,20 @@ struct AttnArgs {
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
 };
 
-static __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU() default / HF "gelu") with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below
+// the bf16 rounding of the stored result): 1 rcp + 1 exp + 6 FMA instead of libm erff's long branchy polynomial
+// (which cost 8.6 us of a 20 us fc1 tile: tools/gemm_diag.py).
+static __device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(z)
+  const float h = 0.5f * x * e;                                                    // x >= 0: x - h ; x < 0: h
+  return x >= 0.f ? x - h : h;
+}
 static __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 template <int ACT>

@@ -18,10 +18,22 @@
 #define BN 128
 #define BK 64
 #define STAGE_BYTES (2 * BM * BK * 2)   // A tile + W tile
-#define LDS_BYTES (128 * 132 * 4)          // two operand stages (64 KiB) < the fp32 epilogue tile (66 KiB)
+#ifndef NSTAGE
+#define NSTAGE 4
+#endif
+static_assert(NSTAGE >= 3 && NSTAGE <= 4, "the mid-iteration prefetch needs a ring of 3 or 4 K tiles");
+#define EPI_BYTES (128 * 132 * 4)            // fp32 epilogue tile, reuses the operand ring
+#define LDS_BYTES (NSTAGE * STAGE_BYTES > EPI_BYTES ? NSTAGE * STAGE_BYTES : EPI_BYTES)
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+#ifdef WFL_GEMM_STAMPS
+// Diagnostic build only (tools/gemm_diag.py): per-block 100 MHz timestamps of the phases, written to a side buffer.
+#define STAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 static __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
@@ -34,6 +46,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  STAMP(0);
   // ---- XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of
   // tiles ordered so that consecutive tiles share the same 128-row A panel.
   const int tiles_n = p.N / BN;
@@ -88,35 +101,82 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
   const bool swap_roles = VT && p.Vt != nullptr && n0 >= p.vt_n0;   // block-uniform
 
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* At = smem + (kt & 1) * STAGE_BYTES + wm * 128;
-    const char* Wt = smem + (kt & 1) * STAGE_BYTES + BM * BK * 2 + wn * 128;
+  // bias for this lane's 4x4 channels (normal roles), fetched before the K loop so its latency is off the epilogue
+  f32x4 bj[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 xa[4], wb[4];
+  for (int j = 0; j < 4; ++j)
+    bj[j] = p.bias ? *(const f32x4*)(p.bias + n0 + wn + j * 16 + (lane >> 4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- main loop: NSTAGE-deep LDS ring of K tiles + software-pipelined fragment reads (one wave per SIMD has no
+  // partner wave to hide LDS latency behind, so the reads of the next half tile are issued under this half's MFMAs).
+  //
+  //   iteration kt, F0 = fragments of (tile kt, k 0..31) already in flight:
+  //     read F1 = (kt, k 32..63) | 16 MFMA on F0
+  //     wait "tile kt+1 landed" (counted vmcnt: every wave issues 8 LDS-DMA loads per tile, later tiles stay in
+  //     flight) ; raw s_barrier ; prefetch tile kt+NSTAGE-1 into the slot of tile kt-1 (the barrier proves every
+  //     wave finished kt-1)
+  //     read F0 = (kt+1, k 0..31) | 16 MFMA on F1
+  //
+  // acc[u][v] = mfma(FA[v], FB[u]); FA rows come from the weight tile and FB rows from the frame tile (D[n][m]),
+  // or the other way round (D[m][n]) for blocks that write V transposed: the roles are just LDS offsets.
+  const int fa_off = (swap_roles ? 0 : BM * BK * 2) + (swap_roles ? wm : wn) * 128;
+  const int fb_off = (swap_roles ? BM * BK * 2 : 0) + (swap_roles ? wn : wm) * 128;
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#define LOAD_FRAGS(FA, FB, slot, s)                                                              \
+  do {                                                                                           \
+    const char* ta_ = smem + (slot) * STAGE_BYTES + fa_off + frag_off[s];                        \
+    const char* tb_ = smem + (slot) * STAGE_BYTES + fb_off + frag_off[s];                        \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) FA[v_] = *(const bf16x8*)(ta_ + v_ * 2048); \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) FB[u_] = *(const bf16x8*)(tb_ + u_ * 2048); \
+  } while (0)
+#define MMA(FA, FB, lo, hi)                                                                      \
+  _Pragma("unroll") for (int q_ = (lo); q_ < (hi); ++q_)                                         \
+    acc[q_ >> 2][q_ & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[q_ & 3], FB[q_ >> 2], acc[q_ >> 2][q_ & 3], 0, 0, 0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)   /* lgkmcnt(0) only; a builtin so hipcc's wait model sees it */
+#define WAIT_TILES(later)                                                        \
+  do {                                                                           \
+    if ((later) >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          \
+    else if ((later) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+  } while (0)
+
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xa[i] = *(const bf16x8*)(At + i * 2048 + frag_off[s]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(Wt + j * 2048 + frag_off[s]);
-      if (VT && swap_roles) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], wb[j], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-      }
-    }
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < nk) stage(t, t);
+  {
+    const int later = (nk - 1 < NSTAGE - 2) ? nk - 1 : NSTAGE - 2;   // tiles issued after tile 0
+    WAIT_TILES(later);
+    __builtin_amdgcn_s_barrier();
+    STAMP(1);
+    LOAD_FRAGS(fa0, fb0, 0, 0);
   }
+  for (int kt = 0; kt < nk; ++kt) {
+    // One straight-line body for every iteration (a peeled last iteration made hipcc rotate the 64 accumulator
+    // registers through v_accvgpr_mov every trip): on the last trip the wait/barrier are trivially satisfied and
+    // the F0 read fetches a stale ring slot that nothing consumes.
+    LGKM0();                                  // F0 (issued half an iteration ago) has arrived
+    LOAD_FRAGS(fa1, fb1, kt % NSTAGE, 1);
+    SB();
+    MMA(fa0, fb0, 0, 16);
+    SB();
+    {
+      const int last = (kt + NSTAGE - 2 < nk - 1) ? kt + NSTAGE - 2 : nk - 1;   // newest tile issued so far
+      WAIT_TILES(last - (kt + 1));
+      __builtin_amdgcn_s_barrier();
+      if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+    }
+    LGKM0();                                  // F1 has arrived
+    LOAD_FRAGS(fa0, fb0, (kt + 1) % NSTAGE, 0);
+    SB();
+    MMA(fa1, fb1, 0, 16);
+    SB();
+  }
+#undef LOAD_FRAGS
+#undef MMA
+#undef SB
+#undef LGKM0
+#undef WAIT_TILES
 
   // ------------------------------------------------------------------ epilogue
   // The accumulators leave through LDS so that HBM sees whole rows: every lane owns 4 channels x 1 frame per MFMA
@@ -127,7 +187,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NC = GLU ? 64 : 128;          // staged columns
   constexpr int EP = NC + 4;                  // pitch in floats
   float* stg = (float*)smem;
+  STAMP(2);
   __syncthreads();                            // all waves are done with the operand stages
+#ifdef WFL_GEMM_STAMPS
+  if (tid == 0 && p.stamps) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    p.stamps[(long)blockIdx.x * 8 + 6] = xcc;
+    p.stamps[(long)blockIdx.x * 8 + 7] = hwid;
+  }
+#endif
   if (VT && swap_roles) {
     // acc[i][j][e]: frame m = wm+16i+4g+e, channel n = wn+16j+c  ->  staged transposed [n][m]
 #pragma unroll
@@ -136,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
       const float bv = p.bias ? p.bias[n0 + nl] : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f32x4 v = acc[i][j];
+        f32x4 v = acc[j][i];                  // swapped roles: acc[u][v] with u = channel tile, v = frame tile
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bv;
         *(f32x4*)(stg + nl * EP + wm + i * 16 + (lane >> 4) * 4) = v;
@@ -178,9 +249,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     if (GLU) {
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
-        const int n = n0 + wn + jp * 32 + (lane >> 4) * 4;        // 'a' rows; gates at n + 16
-        f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) { ba = *(const f32x4*)(p.bias + n); bg = *(const f32x4*)(p.bias + n + 16); }
+        const f32x4 ba = bj[2 * jp], bg = bj[2 * jp + 1];
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[i][2 * jp][e] + ba[e]) * sigmoidf_(acc[i][2 * jp + 1][e] + bg[e]);
@@ -190,8 +259,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int nl = wn + j * 16 + (lane >> 4) * 4;
-        f32x4 v = acc[i][j];
-        if (p.bias) { const f32x4 bb = *(const f32x4*)(p.bias + n0 + nl); v += bb; }
+        f32x4 v = acc[i][j] + bj[j];
         if (cb) { const f32x4 bb = *(const f32x4*)(cb + n0 + nl); v += bb; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
@@ -200,22 +268,48 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
   }
   __syncthreads();
+  STAMP(3);
 
-  // stage 2: thread -> 8 consecutive channels of one frame per pass
+  // stage 2: thread -> 8 consecutive channels of one frame per pass.  All global loads (residual, positional table)
+  // of the 128/RPP passes are issued before the first use so their latencies overlap instead of adding up.
   constexpr int CP = NC / 8;                  // 8-channel chunks per row
   constexpr int RPP = 256 / CP;               // rows per pass
+  constexpr int NP = 128 / RPP;
   const int cidx = tid % CP;
   const int nb = (GLU ? n0 / 2 : n0) + cidx * 8;
   const int nvalid = GLU ? p.n_valid / 2 : p.n_valid;
   if (nb >= nvalid) return;
+  long orow[NP];
+  int tt[NP];
+  bool ok[NP];
+  {
+    const int m = m0 + tid / CP;
+    int b = m / p.P, t = m - b * p.P;
 #pragma unroll
-  for (int pass = 0; pass < 128 / RPP; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
+      ok[pass] = (m + pass * RPP < p.M) && t < p.T;
+      tt[pass] = t;
+      orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
+      t += RPP;
+      if (t >= p.P) { t -= p.P; ++b; }       // RPP <= 32 < P
+    }
+  }
+  // Unconditional loads (a branch per load would make hipcc wait vmcnt(0) after each): rows that are not stored
+  // are halo / tail rows of the residual's frame-row buffer, which exist; the positional row is clamped.
+  bf16x8 rr[NP], pp[NP];
+  if (p.res) {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) rr[pass] = *(const bf16x8*)(p.res + orow[pass] * p.ldres + nb);
+  }
+  if (p.pos) {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass)
+      pp[pass] = *(const bf16x8*)(p.pos + (long)(tt[pass] < p.T ? tt[pass] : p.T - 1) * p.ldpos + nb);
+  }
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    if (!ok[pass]) continue;
     const int r = pass * RPP + tid / CP;
-    const int m = m0 + r;
-    if (m >= p.M) continue;
-    const int b = m / p.P, t = m - b * p.P;
-    if (t >= p.T) continue;
-    const long orow = p.c_lead + (long)b * p.c_pitch + t;
     float v[8];
     {
       const f32x4 v0 = *(const f32x4*)(stg + r * EP + cidx * 8);
@@ -224,17 +318,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
       for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
     }
     if (p.pos) {
-      const bf16x8 pp = *(const bf16x8*)(p.pos + (long)t * p.ldpos + nb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[e]);
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[pass][e]);
     }
     if (p.res) {
-      const bf16x8 rr = *(const bf16x8*)(p.res + orow * p.ldres + nb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[e]) + p.alpha * v[e];
+      for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[pass][e]) + p.alpha * v[e];
     }
     if (OUTF32) {
-      float* o = (float*)p.C + orow * p.ldc + nb;
+      float* o = (float*)p.C + orow[pass] * p.ldc + nb;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if (nb + e < nvalid) o[e] = v[e];
@@ -242,14 +334,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-      *(bf16x8*)((bf16_t*)p.C + orow * p.ldc + nb) = o;
+      *(bf16x8*)((bf16_t*)p.C + orow[pass] * p.ldc + nb) = o;
     } else {
-      bf16_t* o = (bf16_t*)p.C + orow * p.ldc + nb;
+      bf16_t* o = (bf16_t*)p.C + orow[pass] * p.ldc + nb;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if (nb + e < nvalid) o[e] = f2bf(v[e]);
     }
   }
+  STAMP(4);
 }
 
 template <int ACT, bool GLU, bool OUTF32, bool VT>
