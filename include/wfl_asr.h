@@ -109,6 +109,10 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
                     int64_t workspace_bytes, int32_t* ids, int32_t* argmax, float* maxprob, float* offsets,
                     float* logits, float* hidden, void* stream);
 
+/* Synchronise `stream` and report deferred device-side errors of the last wfl_forward on this workspace (today: a
+ * timed-out inter-workgroup wait of the persistent BiLSTM kernel).  Optional; 0 = ok. */
+int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_t B, int32_t L, void* stream);
+
 /* ---- single stages, exported for unit parity tests and profiling ---- */
 
 /* Replaces WhisperFeatureExtractor.__call__ at model.py:153-154 (HF feature_extraction_whisper.py:135-168).

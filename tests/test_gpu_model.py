@@ -205,6 +205,60 @@ def test_full_size_properties_cfg2():
     _note("cfg2_full", distinct_tags=int(full.ids.unique().numel()), o_frac=float((full.ids == labels.index("O")).float().mean()))
 
 
+@pytest.mark.parametrize("units", [None, "8"])
+def test_bilstm_tiny_matches_reference_golden(units, golden_dir, monkeypatch):
+    """whisper_tiny golden = the reference's full default head (2-layer BiLSTM, 2 Conformer, 2 dilated convs), full
+    tensors.  units=8 forces 4 workgroups per direction so the inter-workgroup hand-off is exercised at H=32."""
+    if units:
+        monkeypatch.setenv("WFL_LSTM_UNITS", units)
+    g = np.load(os.path.join(golden_dir, "whisper_tiny.npz"))
+    cfg = GOLDEN_CASES["whisper_tiny"]()
+    m, labels, sd_np = _build(cfg, int(g["n_phonemes"]), int(g["seed"]))
+    B, L = len(g["lang_id"]), int(g["L"])
+    wav = synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
+    out = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True, want_hidden=True)
+    m.check(B, L)
+    h_err = np.abs(out.hidden.cpu().numpy() - g["hidden"])
+    assert h_err.max() <= 0.08
+    _check_decisions("tiny_bilstm_" + str(units), out, torch.from_numpy(g["logits"]), torch.from_numpy(g["offsets"]),
+                     labels.index("O"), 0.5)
+    again = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True)
+    assert torch.equal(again.logits, out.logits)
+
+
+def test_bilstm_base_matches_reference_golden(golden_dir):
+    """Whisper-base + the default config.yaml head (H=256: 4 workgroups per direction), B=1, 18.75 s clip."""
+    g = np.load(os.path.join(golden_dir, "whisper_base_full.npz"))
+    cfg = GOLDEN_CASES["whisper_base_full"]()
+    m, labels, sd_np = _build(cfg, int(g["n_phonemes"]), int(g["seed"]))
+    B, L = len(g["lang_id"]), int(g["L"])
+    wav = synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
+    thr = 0.5
+    out = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=thr, want_logits=True)
+    m.check(B, L)
+    r = g["rows"]
+    lg_err = np.abs(out.logits.cpu().numpy()[:, r] - g["logits_rows"])
+    mp_err = np.abs(out.maxprob.cpu().numpy() - g["maxprob"])
+    of_err = np.abs(out.offsets.cpu().numpy() - g["offsets"])
+    safe = (g["margin"] > TAU) & (np.abs(g["maxprob"] - thr) > 0.08)
+    o_id = labels.index("O")
+    ids_ref = np.where(g["maxprob"] < thr, o_id, g["argmax"].astype(np.int64))
+    arg_bad = int((out.argmax.cpu().numpy() != g["argmax"])[g["margin"] > TAU].sum())
+    ids_bad = int((out.ids.cpu().numpy() != ids_ref)[safe].sum())
+    _note("golden_base_full", logits_max=lg_err.max(), logits_mean=lg_err.mean(), maxprob_max=mp_err.max(),
+          offsets_max=of_err.max(), safe_frac=safe.mean(), argmax_bad=arg_bad, ids_bad=ids_bad)
+    assert lg_err.max() <= 0.6 and lg_err.mean() <= 0.08
+    assert mp_err.max() <= 0.08 and of_err.max() <= 0.03
+    assert arg_bad == 0 and ids_bad == 0 and safe.mean() >= 0.60
+    # batch of 20 clips = 2 clip groups (one partial): clip 0 is bit-identical to the B=1 run
+    wav20 = np.concatenate([wav, synth.make_batch(7000, 19, L, seed=3)])
+    lang20 = np.concatenate([g["lang_id"], np.arange(19) % 2]).astype(np.int64)
+    big = m.label(torch.from_numpy(wav20).cuda(), lang20, threshold=thr, want_logits=True)
+    m.check(20, L)
+    assert torch.equal(big.logits[0], out.logits[0])
+    assert bool(torch.isfinite(big.logits).all())
+
+
 def test_graph_replay_is_bit_identical():
     cfg = _tiny()
     m, labels, _ = _build(cfg, 5, seed=24)

@@ -327,9 +327,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
     if (OUTF32) {
       float* o = (float*)p.C + orow[pass] * p.ldc + nb;
+      if (nb + 8 <= nvalid && (p.ldc & 3) == 0) {
+        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (nb + e < nvalid) o[e] = v[e];
+        for (int e = 0; e < 8; ++e)
+          if (nb + e < nvalid) o[e] = v[e];
+      }
     } else if (nb + 8 <= nvalid) {
       bf16x8 o;
 #pragma unroll

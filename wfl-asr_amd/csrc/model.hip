@@ -41,6 +41,20 @@ struct TagArgs {
   float* offsets;
 };
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
+
+struct LstmArgs {
+  const float* gx; long ldgx;
+  const bf16_t* whh;
+  bf16_t* out; long ldo;
+  long lead;
+  int B, T, P, H, U, G;
+  bf16_t* hx;
+  unsigned* counters;
+  unsigned* error;
+};
+int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s);
+int wfl_lstm_units_per_wg(int H);
+long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
 int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s);
 int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s);
@@ -112,6 +126,9 @@ struct wfl_model {
   // head
   Lin lang;
   float* lang_table = nullptr;    // [num_languages][d]
+  std::vector<Lin> lstm_in;       // per layer: both directions' input projection, rows [dir][unit][gate]
+  std::vector<bf16_t*> lstm_whh;  // per layer: [2][G][4U][H]
+  int lstm_U = 0;
   std::vector<ConfLayer> conf;
   std::vector<Lin> dil;
   Lin cls, off1;
@@ -371,7 +388,41 @@ static int finalize_head(wfl_model* m, Packer& P) {
     m->lang = P.pack(rows, d, d, nullptr);
     m->lang_table = P.upload(table);
   }
-  if (a.enable_bilstm) { if (P.err.empty()) P.err = "BiLSTM head is not built into this library yet"; }
+  if (a.enable_bilstm) {
+    // nn.LSTM(d, d/2, num_layers, bidirectional): model.py:104-111.  Gate rows i|f|g|o (blocks of H) are reordered
+    // unit-major / gate-minor for the recurrence kernel (lstm.hip); b_ih + b_hh fold into the projection bias.
+    const int H = d / 2;
+    m->lstm_U = wfl_lstm_units_per_wg(H);
+    if (m->lstm_U <= 0 && P.err.empty()) P.err = "BiLSTM hidden size " + std::to_string(H) + " is not supported";
+    const int U = std::max(m->lstm_U, 1), G = H / U;
+    for (int layer = 0; layer < a.bilstm_layers && P.err.empty(); ++layer) {
+      const int din = d;      // layer 0: encoder width d; deeper layers: 2H = d
+      std::vector<float> rows((size_t)8 * H * din), bias((size_t)8 * H);
+      std::vector<uint16_t> whh((size_t)2 * 4 * H * H);
+      for (int dir = 0; dir < 2; ++dir) {
+        const std::string suf = "_l" + std::to_string(layer) + (dir ? "_reverse" : "");
+        const HostTensor* wih = P.get("bilstm.weight_ih" + suf, {4 * H, din});
+        const HostTensor* whh_t = P.get("bilstm.weight_hh" + suf, {4 * H, H});
+        const HostTensor* bih = P.get("bilstm.bias_ih" + suf, {4 * H});
+        const HostTensor* bhh = P.get("bilstm.bias_hh" + suf, {4 * H});
+        if (!wih || !whh_t || !bih || !bhh) break;
+        for (int u = 0; u < H; ++u)
+          for (int gate = 0; gate < 4; ++gate) {
+            const int src = gate * H + u;
+            const size_t dst = (size_t)dir * 4 * H + 4 * u + gate;
+            memcpy(&rows[dst * din], &wih->data[(size_t)src * din], sizeof(float) * din);
+            bias[dst] = bih->data[src] + bhh->data[src];
+            // slice-major packing: [dir][slice][4*u_local + gate][H]
+            const int sl = u / U, ul = u % U;
+            const size_t wrow = ((size_t)(dir * G + sl) * 4 * U) + 4 * ul + gate;
+            for (int k = 0; k < H; ++k) whh[wrow * H + k] = f32_to_bf16_bits(whh_t->data[(size_t)src * H + k]);
+          }
+      }
+      if (!P.err.empty()) break;
+      m->lstm_in.push_back(P.pack(rows, 8 * H, din, &bias));
+      m->lstm_whh.push_back((bf16_t*)P.upload(whh));
+    }
+  }
   m->conf.resize(a.n_conformer);
   const int x = a.conformer_ff_expansion, kk = a.conformer_kernel;
   for (int i = 0; i < a.n_conformer; ++i) {
@@ -467,7 +518,7 @@ struct Plan {
   long R, R2;
   int d, ffw;
   // byte offsets
-  long mel, c1, X, Y, ATT, QK, VT, FF, raw, clipmax, logits, logits2, offs2, total;
+  long mel, c1, X, Y, ATT, QK, VT, FF, raw, clipmax, logits, logits2, offs2, gx, lstm_x, total;
 };
 
 static Plan make_plan(const wfl_model* m, int B, int L) {
@@ -498,6 +549,11 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
   p.logits = take((long)B * p.T * a.num_classes * 4);
   p.logits2 = take((long)B * p.T * a.num_classes * 4);
   p.offs2 = take((long)B * p.T * 2 * 4);
+  p.gx = p.lstm_x = 0;
+  if (a.enable_bilstm) {
+    p.gx = take(p.R * 4L * p.d * 4);                       // fp32 [rows][8H]
+    p.lstm_x = take(wfl_lstm_exchange_bytes(p.d / 2, B));
+  }
   p.total = off;
   return p;
 }
@@ -696,6 +752,22 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
              false, false, nullptr, 0, nullptr, 0, m->lang_table, idx, d);
       H = X; S = Y;
     }
+    if (a.enable_bilstm) {
+      const int Hh = d / 2;
+      float* GX = (float*)(R.ws + p.gx);
+      for (int layer = 0; layer < a.bilstm_layers; ++layer) {
+        R.gemm(H + (long)p.lead * d, d, m->lstm_in[layer], (int)Mrows, p.P, p.T, GX, 8 * Hh, p.lead, p.P, WFL_ACT_NONE, nullptr, 0,
+               1.f, 0, 0, false, true);
+        if (R.rc) return R.rc;
+        LstmArgs la{};
+        la.gx = GX; la.ldgx = 8 * Hh; la.whh = m->lstm_whh[layer]; la.out = S; la.ldo = d; la.lead = p.lead;
+        la.B = B; la.T = p.T; la.P = p.P; la.H = Hh; la.U = m->lstm_U;
+        const int lr = wfl_launch_lstm(la, R.ws + p.lstm_x, R.s);
+        if (lr) return fail(lr, lr == -5 ? "BiLSTM: batch too large for one resident launch (max 256 / (2 * H/U) groups of 16 clips)"
+                                          : "lstm launch failed (" + std::to_string(lr) + ")");
+        std::swap(H, S);
+      }
+    }
     for (int i = 0; i < a.n_conformer; ++i) {
       const ConfLayer& C = m->conf[i];
       // x = x + 0.5 * FF1(x)
@@ -765,6 +837,20 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     }
   }
   return R.rc;
+}
+
+int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_t B, int32_t L, void* stream) {
+  if (!m || !m->finalized || !workspace) return fail(-1, "wfl_check: bad argument");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  if (!m->a.enable_bilstm) return 0;
+  const Plan p = make_plan(m, B, L);
+  if (workspace_bytes < p.total) return fail(-1, "wfl_check: workspace too small");
+  const long groups = (B + 15) / 16;
+  const long hx_bytes = 2L * groups * 2 * 16 * (m->a.d_model / 2) * 2;
+  unsigned err = 0;
+  HIPCHK(hipMemcpy(&err, (char*)workspace + p.lstm_x + hx_bytes + 2 * groups * sizeof(unsigned), sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (err) return fail(-20, "BiLSTM recurrence: an inter-workgroup wait timed out (results of the last forward are invalid)");
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single-op exports

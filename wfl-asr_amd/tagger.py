@@ -218,6 +218,14 @@ class BIOPhonemeTagger:
         g["graph"].replay()
         return g["out"]
 
+    def check(self, B: int, L: int, device=None):
+        """Synchronise and raise if the last forward recorded a device-side error (BiLSTM hand-off time-out)."""
+        dev = torch.device(device) if device is not None else self._ws.device
+        ws = self._workspace(B, L, dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(self._lib.wfl_check(self._handle, _ptr(ws), ws.numel(), B, L, C.c_void_p(stream)), "wfl_check")
+
     def forward(self, input_values, lang_id=None, max_label_len=None):
         """Reference contract (model.py:148-194): returns (logits [B,T,C] f32, offsets [B,T,2] f32)."""
         if max_label_len is not None:
