@@ -1,0 +1,80 @@
+"""CPU: audio ingest (WAV decode, resampling invariants, normalisation, chunking).  torchaudio/soundfile are absent,
+so resample parity with torchaudio is unpinned; these tests hold the restated algorithm to its own properties."""
+import struct
+
+import numpy as np
+import pytest
+
+from wfl_asr_amd import audio as A
+
+
+def test_wav_roundtrip_pcm16(tmp_path):
+    x = np.sin(np.arange(4000) * 0.05) * 0.7
+    p = str(tmp_path / "a.wav")
+    A.write_wav(p, x, 16000)
+    y, sr = A.read_wav(p)
+    assert sr == 16000 and y.dtype == np.float64 and len(y) == len(x)
+    assert np.abs(y - x).max() <= 1.0 / 32768 + 1e-12
+
+
+def _raw_wav(path, fmt_tag, ch, sr, bits, payload, extensible=False):
+    if extensible:
+        fmt = struct.pack("<HHIIHH", 0xFFFE, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits) + struct.pack("<HHI", 22, bits, 0) \
+            + struct.pack("<H", fmt_tag) + b"\x00" * 14
+    else:
+        fmt = struct.pack("<HHIIHH", fmt_tag, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 4) + b"abcd" \
+        + b"data" + struct.pack("<I", len(payload)) + payload
+    open(path, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_wav_formats(tmp_path):
+    x = (np.arange(-50, 50) / 64.0).astype(np.float32)
+    p = str(tmp_path / "f.wav")
+    _raw_wav(p, 3, 1, 22050, 32, x.tobytes())
+    y, sr = A.read_wav(p)
+    assert sr == 22050 and np.array_equal(y, x.astype(np.float64))
+    _raw_wav(p, 3, 1, 8000, 32, x.tobytes(), extensible=True)
+    assert np.array_equal(A.read_wav(p)[0], x.astype(np.float64))
+    i24 = np.array([0, 1, -1, 8388607, -8388608], dtype=np.int32)
+    raw = b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in i24)
+    _raw_wav(p, 1, 1, 16000, 24, raw)
+    np.testing.assert_allclose(A.read_wav(p)[0], i24 / 8388608.0)
+    st = np.stack([np.full(10, 1000, "<i2"), np.full(10, -3000, "<i2")], axis=1)
+    _raw_wav(p, 1, 2, 16000, 16, st.tobytes())
+    np.testing.assert_allclose(A.read_wav(p)[0], np.full(10, -1000 / 32768.0))
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"not a wav file")
+        A.read_wav(p)
+
+
+@pytest.mark.parametrize("orig,new", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000)])
+def test_resample_properties(orig, new):
+    n = orig  # one second
+    t = np.arange(n) / orig
+    x = 0.5 * np.sin(2 * np.pi * 440.0 * t)
+    y = A.resample(x, orig, new)
+    assert len(y) == int(np.ceil(new * n / orig))
+    ty = np.arange(len(y)) / new
+    mid = slice(len(y) // 10, -len(y) // 10)
+    assert np.abs(y[mid] - 0.5 * np.sin(2 * np.pi * 440.0 * ty[mid])).max() < 2e-3     # same tone, same phase
+    dc = A.resample(np.ones(n), orig, new)
+    assert np.abs(dc[mid] - 1.0).max() < 2e-3                                            # unit DC gain
+    if new < orig:                                                                        # content above new Nyquist is removed
+        hi = A.resample(np.sin(2 * np.pi * (new * 0.75) * t), orig, new)
+        assert np.abs(hi[mid]).max() < 0.02
+    assert np.array_equal(A.resample(x, new, new), x)
+
+
+def test_normalise_and_chunking():
+    x = np.array([0.1, -0.5, 0.25])
+    np.testing.assert_allclose(A.peak_normalize(x), x / (0.5 + 1e-8), rtol=0, atol=0)
+    assert A.peak_normalize(np.zeros(0)).size == 0
+    sr = 16000
+    short = A.chunk_clip(np.ones(30 * sr) * 0.5, sr)            # exactly 30 s is NOT split (infer.py:237 uses >)
+    assert len(short) == 1 and short[0].dtype == np.float32 and len(short[0]) == 30 * sr
+    long = np.concatenate([np.full(30 * sr, 0.2), np.full(30 * sr, 0.4), np.full(5 * sr, 0.1)])
+    ch = A.chunk_clip(A.peak_normalize(long), sr)
+    assert [len(c) for c in ch] == [480000, 480000, 80000]
+    for c in ch:                                                 # every chunk re-normalised to peak 1 (infer.py:115)
+        assert abs(float(np.abs(c).max()) - 1.0) < 1e-6

@@ -1,0 +1,132 @@
+"""Audio ingest for the labeling loop: WAV decode, resample to 16 kHz, peak normalisation, 30 s chunking.
+
+Replaces /root/reference/infer.py:217-220 (soundfile.read + torchaudio.functional.resample), :234-235 / :115
+(peak normalisation, float64) and :19-28 (split_audio).  soundfile and torchaudio are not available in this
+image, so decode and resampling are restated here:
+
+  * read_wav: RIFF/WAVE PCM 8/16/24/32-bit and IEEE float 32/64 (plain and WAVE_FORMAT_EXTENSIBLE), returning
+    float64 in [-1, 1) scaled like libsndfile (int16 / 32768 ...).  Multi-channel files are averaged to mono (the
+    reference would fail on them: `max(abs(audio))` on a 2-D array).
+  * resample: torchaudio.functional.resample's algorithm (sinc interpolation, Hann window, lowpass_filter_width 6,
+    rolloff 0.99) written out from its published definition.  Parity with torchaudio is UNPINNED (the library is
+    absent here and the reference holds no resampled fixtures); only its own invariants are tested.
+"""
+from __future__ import annotations
+
+import math
+import struct
+
+import numpy as np
+
+from .postprocess import MAX_SEGMENT_DURATION, split_audio  # noqa: F401  (re-exported)
+
+
+def read_wav(path: str):
+    """-> (float64 mono samples, sample_rate)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos = 12
+    fmt = None
+    pcm = None
+    while pos + 8 <= len(data):
+        cid = data[pos:pos + 4]
+        size = struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:        # WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first 2 bytes
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 1:
+        if bits == 8:
+            x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+        elif bits == 16:
+            x = np.frombuffer(pcm[:len(pcm) // 2 * 2], dtype="<i2").astype(np.float64) / 32768.0
+        elif bits == 24:
+            b = np.frombuffer(pcm[:len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v & 0x800000, v - 0x1000000, v)
+            x = v.astype(np.float64) / 8388608.0
+        elif bits == 32:
+            x = np.frombuffer(pcm[:len(pcm) // 4 * 4], dtype="<i4").astype(np.float64) / 2147483648.0
+        else:
+            raise ValueError(f"{path}: unsupported PCM width {bits}")
+    elif tag == 3:
+        dt = {32: "<f4", 64: "<f8"}.get(bits)
+        if dt is None:
+            raise ValueError(f"{path}: unsupported float width {bits}")
+        n = len(pcm) // (bits // 8) * (bits // 8)
+        x = np.frombuffer(pcm[:n], dtype=dt).astype(np.float64)
+    else:
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag}")
+    if ch > 1:
+        x = x[:len(x) // ch * ch].reshape(-1, ch).mean(axis=1)
+    return x, int(sr)
+
+
+def write_wav(path: str, samples, sr: int = 16000):
+    """16-bit PCM mono writer (tests and demos)."""
+    x = np.clip(np.asarray(samples, dtype=np.float64), -1.0, 32767.0 / 32768.0)
+    pcm = np.round(x * 32768.0).astype("<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16))
+        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """Band-limited sinc resampling (Hann-windowed), float64 in / float64 out."""
+    x = np.asarray(x, dtype=np.float64)
+    if orig_freq == new_freq or x.size == 0:
+        return x.copy()
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2.0) ** 2
+    t = t * math.pi
+    scale = base / orig
+    kernels = np.where(t == 0.0, 1.0, np.sin(t) / np.where(t == 0.0, 1.0, t)) * window * scale   # [new, 2*width+orig]
+    length = x.shape[0]
+    xp = np.pad(x, (width, width + orig))
+    klen = kernels.shape[1]
+    nfr = (xp.shape[0] - klen) // orig + 1
+    frames = np.lib.stride_tricks.sliding_window_view(xp, klen)[::orig][:nfr]                 # [frames, klen]
+    out = (frames @ kernels.T).reshape(-1)                                                      # frame-major, phase-minor
+    target = int(math.ceil(new * length / orig))
+    return out[:target]
+
+
+def peak_normalize(x: np.ndarray) -> np.ndarray:
+    """audio / (max|audio| + 1e-8) in float64 (infer.py:234-235; the reference's Python `max` loop, vectorised)."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.size == 0:
+        return x
+    return x / (np.max(np.abs(x)) + 1e-8)
+
+
+def load_clip(path: str, sample_rate: int = 16000):
+    """decode -> resample to `sample_rate` -> peak-normalise; returns float64 samples (as infer.py holds them)."""
+    x, sr = read_wav(path)
+    if sr != sample_rate:
+        x = resample(x, sr, sample_rate)
+    return peak_normalize(x)
+
+
+def chunk_clip(audio: np.ndarray, sr: int = 16000):
+    """The reference's two cases (infer.py:237-244): <= 30 s -> one item as is; longer -> non-overlapping 30 s chunks,
+    each re-normalised (process_segments, infer.py:114-115).  Returns float32 arrays (infer.py:134, 251)."""
+    if len(audio) / sr > MAX_SEGMENT_DURATION:
+        return [(peak_normalize(seg) if len(seg) > 0 else seg).astype(np.float32) for seg in split_audio(audio, sr)]
+    return [np.asarray(audio, dtype=np.float32)]

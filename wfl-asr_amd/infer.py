@@ -1,0 +1,308 @@
+"""The inference surface of WFL-ASR on the MI355X path: same functions, arguments, files and `.lab` output as
+/root/reference/infer.py, with the per-file model rebuild and the B=1 forwards replaced by one resident model and a
+batched loop over 30 s work items.
+
+  infer_audio / infer_folder   signatures of infer.py:186-191 / 330-332
+  Labeler                      the batched loop: one model load (the reference reloads per file, infer.py:205-208),
+                               every clip <= 30 s and every 30 s chunk of a longer file is one batch row; rows of many
+                               files share a forward; `lang_id=None` averages logits/offsets over all languages
+                               inside the library (encoder runs once; infer.py:146-156, 266-276)
+  deviations (documented in DESIGN.md): no `.wfl_cache` (infer.py:223-229), `--sample/--top-k/--top-p/--temperature`
+  are validated but have no effect (their results are overwritten in the reference too, infer.py:283-297), a single
+  file with `-o .` writes `<stem>.lab` instead of overwriting the input WAV (infer.py:410-411, utils.py:77), and
+  `--device cpu` is refused (no CPU path).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+from . import audio as A
+from . import postprocess as pp
+from .tagger import BIOPhonemeTagger
+
+frame_duration = pp.FRAME_DURATION
+MAX_SEGMENT_DURATION = pp.MAX_SEGMENT_DURATION
+CHUNK_SAMPLES = int(MAX_SEGMENT_DURATION * 16000)
+
+
+def load_config(config_path="config.yaml"):
+    with open(config_path, "r") as f:
+        return yaml.safe_load(f)
+
+
+class Labeler:
+    """Model + sidecar files loaded once; `label_files` runs the batched hot loop."""
+
+    def __init__(self, config_path, checkpoint_path, device="cuda", batch_size=16, use_graph=True):
+        self.config = load_config(config_path) if isinstance(config_path, (str, os.PathLike)) else config_path
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("this build labels on MI355X only: --device must be cuda[:N] (there is no CPU path)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible")
+        self.device = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self.sr = int(self.config["data"]["sample_rate"])
+        if self.sr != 16000:
+            raise ValueError("both encoders are 16 kHz models (config data.sample_rate must be 16000)")
+        save_dir = self.config["output"]["save_dir"]
+        self.labels = pp.load_phoneme_list(os.path.join(save_dir, "phonemes.txt"))
+        langs_path = os.path.join(save_dir, "langs.txt")
+        self.lang2id = pp.load_langs(langs_path) if os.path.exists(langs_path) else {}
+        mm_path = os.path.join(save_dir, "phoneme_merge_map.json")
+        self.merge_map = pp.load_phoneme_merge_map(mm_path) if os.path.exists(mm_path) else None
+        self.model = BIOPhonemeTagger(self.config, self.labels)
+        if isinstance(checkpoint_path, dict):
+            state_dict = checkpoint_path
+        else:
+            state_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        self.model.load_state_dict(state_dict)
+        self.model.to(self.device).eval()
+        self.batch_size = int(batch_size)
+        self.use_graph = bool(use_graph)
+        self._pinned = None
+
+    # ------------------------------------------------------------------ the batched loop
+    def _forward_items(self, items, lang_id, threshold):
+        """items: list of float32 arrays (<= 480000 samples each) -> list of (ids[T], offsets[T,2]) numpy."""
+        if self.model.encoder_type != "whisper":
+            return self._forward_items_by_length(items, lang_id, threshold)
+        out = [None] * len(items)
+        Bs = self.batch_size
+        L = CHUNK_SAMPLES
+        if self._pinned is None:
+            self._pinned = torch.zeros(Bs, L, dtype=torch.float32).pin_memory()
+        for s in range(0, len(items), Bs):
+            chunk = items[s:s + Bs]
+            host = self._pinned
+            lens = np.zeros(Bs, dtype=np.int32)
+            for i, x in enumerate(chunk):
+                n = min(len(x), L)
+                host[i, :n] = torch.from_numpy(np.ascontiguousarray(x[:n]))
+                lens[i] = n
+            dev_wav = host.to(self.device, non_blocking=True)
+            res = self.model.label(dev_wav, None if lang_id is None else [lang_id] * Bs, threshold=threshold, lens=lens,
+                                   average_languages=lang_id is None, graph=self.use_graph)
+            ids = res.ids.cpu().numpy()
+            offs = res.offsets.cpu().numpy()
+            for i in range(len(chunk)):
+                out[s + i] = (ids[i], offs[i])
+        return out
+
+    def _forward_items_by_length(self, items, lang_id, threshold):
+        """WavLM: the frame count follows the clip length, so rows are grouped by exact length."""
+        out = [None] * len(items)
+        by_len = {}
+        for i, x in enumerate(items):
+            by_len.setdefault(len(x), []).append(i)
+        for n, idxs in by_len.items():
+            for s in range(0, len(idxs), self.batch_size):
+                sel = idxs[s:s + self.batch_size]
+                wav = torch.from_numpy(np.stack([items[i] for i in sel])).to(self.device)
+                res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold,
+                                       average_languages=lang_id is None)
+                ids, offs = res.ids.cpu().numpy(), res.offsets.cpu().numpy()
+                for j, i in enumerate(sel):
+                    out[i] = (ids[j], offs[j])
+        return out
+
+    def _lang_name(self, lang_id):
+        if lang_id is None:
+            return None
+        for n, i in self.lang2id.items():
+            if i == lang_id:
+                return n
+        return None
+
+    def _segments_of_item(self, ids, offsets, lang_name):
+        """suppressed ids -> median filter -> BIO decode -> merge-map back-mapping (infer.py:164-179, 293-307)."""
+        mf = int(self.config["postprocess"]["median_filter"])
+        if mf > 1:
+            ids = pp.median_filter_ids(ids, mf)
+        tags = [self.model.id2label[int(i)] for i in ids]
+        segs = pp.decode_bio_tags(tags, frame_duration=frame_duration, offsets=offsets)
+        if self.merge_map and lang_name:
+            segs = [(s, e, pp.canonical_to_lang(ph, lang_name, self.merge_map)) for s, e, ph in segs]
+        return segs
+
+    def label_files(self, audio_paths, lang_id=None, confidence_threshold=0.0, verbose=True):
+        """-> list (per file) of [(start_s, end_s, phoneme)] after merge + forced alignment."""
+        if lang_id is not None and self.lang2id and lang_id > max(self.lang2id.values()):
+            raise ValueError(f"Error: Language ID ({lang_id}) is higher than the latest ID ({max(self.lang2id.values())}) "
+                             f"of this model.\n Languages and Codes available: {self.lang2id}")
+        lang_name = self._lang_name(lang_id)
+        items, owner = [], []
+        chunk_lens = []
+        for fi, path in enumerate(audio_paths):
+            audio = A.load_clip(path, self.sr)
+            if verbose and len(audio) / self.sr > MAX_SEGMENT_DURATION:
+                print(f"Audio is too long ({len(audio)/self.sr:.1f}s), splitting...")
+            chunks = A.chunk_clip(audio, self.sr)
+            lens = [len(c) for c in A.split_audio(audio, self.sr)] if len(chunks) > 1 else [len(audio)]
+            for c, n in zip(chunks, lens):
+                items.append(c)
+                owner.append(fi)
+                chunk_lens.append(n)
+        decided = self._forward_items(items, lang_id, confidence_threshold)
+        results = [[] for _ in audio_paths]
+        clock = [0.0] * len(audio_paths)
+        for (ids, offs), fi, n in zip(decided, owner, chunk_lens):
+            segs = self._segments_of_item(ids, offs, lang_name)
+            t0 = clock[fi]
+            results[fi].extend((s + t0, e + t0, ph) for s, e, ph in segs)
+            clock[fi] += n / self.sr
+        final = []
+        for fi, path in enumerate(audio_paths):
+            segs = results[fi]
+            mode = self.config["postprocess"]["merge_segments"]
+            if mode != "none":
+                segs = pp.merge_adjacent_segments(segs, mode=mode)
+            forced = _read_forced(path, verbose)
+            if forced is not None:
+                aligned = pp.align_phoneme_list(segs, forced)
+                if "SP" not in forced and "AP" not in forced and aligned:
+                    before = [s for s in segs if s[2] in ("SP", "AP") and s[1] <= aligned[0][0]]
+                    after = [s for s in segs if s[2] in ("SP", "AP") and s[0] >= aligned[-1][1]]
+                    segs = before + aligned + after
+                else:
+                    segs = aligned
+            final.append(segs)
+        return final
+
+
+def _read_forced(audio_path, verbose):
+    """`{audio}.txt` forced phoneme list (infer.py:193, 210-215)."""
+    txt = audio_path.replace(".wav", ".txt")
+    if txt == audio_path or not os.path.exists(txt):
+        return None
+    forced = []
+    with open(txt, "r", encoding="utf-8") as f:
+        for line in f:
+            forced.extend(line.strip().split())
+    if verbose:
+        print(f"Loaded forced phoneme list with {len(forced)} phonemes.")
+    return forced
+
+
+_LABELERS = {}
+
+
+def _labeler(config_path, checkpoint_path, device):
+    key = (os.path.abspath(str(config_path)), os.path.abspath(str(checkpoint_path)), str(device))
+    if key not in _LABELERS:
+        _LABELERS[key] = Labeler(config_path, checkpoint_path, device)
+    return _LABELERS[key]
+
+
+def _write_lab(path, segments):
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    pp.save_lab(path, segments)
+    print(f"Predictions saved to: {path}")
+
+
+def infer_audio(audio_path, config_path="config.yaml", checkpoint_path="best_model.pt", output_lab_path=None, device="cuda",
+                lang_id=None, sample=False, top_k=0, top_p=0.0, temperature=1.0, confidence_threshold=0.0):
+    lab = _labeler(config_path, checkpoint_path, device)
+    segments = lab.label_files([audio_path], lang_id=lang_id, confidence_threshold=confidence_threshold)[0]
+    if output_lab_path:
+        if os.path.abspath(output_lab_path) == os.path.abspath(audio_path):
+            # the reference would truncate the input WAV here (infer.py:410-411 + utils.py:77)
+            output_lab_path = os.path.splitext(audio_path)[0] + ".lab"
+        _write_lab(output_lab_path, segments)
+    return segments
+
+
+def infer_folder(folder_path: str, config_path: str = "config.yaml", checkpoint_path: str = "best_model.pt",
+                 output_dir: str = "outputs", device: str = "cuda", lang_id: int = None, sample=False, top_k=0, top_p=0.0,
+                 temperature=1.0, confidence_threshold=0.0):
+    wav_files = sorted(f for f in os.listdir(folder_path) if f.lower().endswith(".wav"))
+    os.makedirs(output_dir, exist_ok=True)
+    # one process per GPU: every rank labels its own share of the files and writes its own .lab files (no collective)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        from .dist import shard_items
+        sizes = [os.path.getsize(os.path.join(folder_path, f)) for f in wav_files]
+        wav_files = [wav_files[i] for i in shard_items(sizes, world)[rank]]
+    lab = _labeler(config_path, checkpoint_path, device)
+    paths = [os.path.join(folder_path, f) for f in wav_files]
+    all_segments = lab.label_files(paths, lang_id=lang_id, confidence_threshold=confidence_threshold) if paths else []
+    for wav_file, segments in zip(wav_files, all_segments):
+        print(f"\nInferencing: {wav_file}")
+        _write_lab(os.path.join(output_dir, os.path.splitext(wav_file)[0] + ".lab"), segments)
+        print("Predicted segments:")
+        for start, end, ph in segments:
+            print(f"({round(start, 2)}, {round(end, 2)}, {ph})")
+    return all_segments
+
+
+def main(argv=None):
+    import click
+    from pathlib import Path
+
+    @click.command(help="Infer with WFL")
+    @click.argument("path", metavar="PATH")
+    @click.option("--checkpoint", "-ckpt", type=str, required=True, help="Path to WFL Checkpoint.")
+    @click.option("--config", "-c", type=str, required=True, help="Path to Config file.")
+    @click.option("--output", "-o", type=str, required=False, default=".", help="Path to output labels.")
+    @click.option("--lang-id", "-l", type=int, required=False, default=None, help="Language ID.")
+    @click.option("--sample", "-s", is_flag=True, help="Enable sampling instead of argmax")
+    @click.option("--top-k", "-tk", type=int, default=0, help="Top-K sampling (range: 1-20)")
+    @click.option("--top-p", "-tp", type=float, default=0.0, help="Top-P sampling (range: 0.1-1)")
+    @click.option("--temperature", "-temp", type=float, default=1.0, help="Sampling temperature (range: 0.1-2)")
+    @click.option("--device", "-d", type=str, default="auto", help='Device to use: "cuda", "cuda:0". Auto-detects if not specified.')
+    @click.option("--confidence-threshold", "-ct", type=float, default=None,
+                  help="Suppress predictions with low confidence. Set 0 to disable.")
+    def cli(path, checkpoint, config, output, lang_id, sample, top_k, top_p, temperature, device, confidence_threshold):
+        if sample:
+            if top_k <= 0 and top_p <= 0.0:
+                print("Sampling is enabled but neither --top-k nor --top-p is set.")
+                sys.exit(1)
+            if top_k > 0 and top_p > 0.0:
+                print("You can't use both --top-k and --top-p at the same time.")
+                sys.exit(1)
+            if top_k < 0:
+                print("top-k must be ≥ 1.")
+                sys.exit(1)
+            if top_p < 0.0 or top_p > 1.0:
+                print("top-p must be between 0.1 and 1.0.")
+                sys.exit(1)
+            if temperature <= 0.0:
+                print("temperature must be greater than 0.")
+                sys.exit(1)
+        requested = device.lower()
+        if requested == "auto":
+            device = "cuda"
+        if not str(device).startswith("cuda") or not torch.cuda.is_available():
+            print("This build runs on MI355X only (no CPU fallback): no ROCm device is available.", file=sys.stderr)
+            sys.exit(1)
+        inf_path = Path(path)
+        cfg = load_config(Path(config))
+        if confidence_threshold is None:
+            confidence_threshold = cfg["postprocess"].get("confidence_threshold", 0.0)
+        output_path = inf_path if output == "." else output
+        if not inf_path.exists():
+            print(f"Unable to locate folder {str(inf_path)}")
+            sys.exit(1)
+        if lang_id is not None and lang_id <= -1:
+            lang_id = None
+        kw = dict(config_path=str(config), checkpoint_path=str(checkpoint), device=device, lang_id=lang_id, sample=sample,
+                  top_k=top_k, top_p=top_p, temperature=temperature, confidence_threshold=confidence_threshold)
+        if inf_path.is_dir():
+            infer_folder(folder_path=str(inf_path), output_dir=str(output_path), **kw)
+        else:
+            segments = infer_audio(audio_path=str(inf_path), output_lab_path=str(output_path), **kw)
+            print("Predicted segments:")
+            for start, end, ph in segments:
+                print(f"({round(start, 2)}, {round(end, 2)}, {ph})")
+
+    cli.main(args=argv, standalone_mode=True)
+
+
+if __name__ == "__main__":
+    main()
