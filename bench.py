@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the HIP-event pass that times every GEMM launch")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one captured HIP graph per step")
     ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (Whisper configs only)")
+    ap.add_argument("--full-head", action="store_true",
+                    help="Whisper-base + the reference's default config.yaml head (2-layer BiLSTM, 2 Conformer, 2 dilated convs)")
     return ap.parse_args()
 
 
@@ -117,7 +119,7 @@ def main():
     from wfl_asr_amd.tagger import BIOPhonemeTagger
     from wfl_asr_amd.dist import gather_tags
 
-    cfg = synth.baseline_config(args.config_index)
+    cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(args.config_index)
     labels = synth.make_labels(70)
     sd_np = synth.make_state_dict(cfg, len(labels), seed=1)
     model = BIOPhonemeTagger(cfg, labels)
@@ -212,8 +214,10 @@ def main():
             "metric": "audio_seconds_labeled_per_sec_per_node", "value": audio_s / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %s + %d Conformer blocks, %d x 30 s clips per GPU" % (
-                args.config_index, cfg["model"]["whisper_model"], cfg["model"]["num_conformer_layers"], B),
+            "config": {"workload": ("default config.yaml head: " if args.full_head else "BASELINE configs[%d]: " % args.config_index)
+                       + "%s + %s%d Conformer blocks%s, %d x 30 s clips per GPU" % (
+                cfg["model"]["whisper_model"], "2-layer BiLSTM + " if cfg["model"]["enable_bilstm"] else "",
+                cfg["model"]["num_conformer_layers"], " + dilated convs" if cfg["model"]["enable_dilated_conv"] else "", B),
                 "clips_per_gpu": B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": T, "tags": len(labels),
                 "parallelism": f"clip-sharded dp{world}", "launch": "hip graph replay" if use_graph else "eager"},
             "roofline": roof,
