@@ -48,6 +48,21 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 note); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return {"hbm_bytes_per_launch": d["gemm_family_hbm_mb_per_launch"] * 1e6, "source": os.path.relpath(files[-1], ROOT)}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores() -> int:
     """Cores this process may actually use: the cgroup CPU quota when there is one (the GPU box hands a 1-GPU job a
     share of the host, not all 256 hardware threads), else the affinity mask."""
@@ -199,7 +214,7 @@ def main():
                 "timing": "HIP events around every GEMM launch, same %d steps re-run eagerly after the timed region "
                           "(%.3f ms/step with events)" % (args.steps, eager_ms),
                 "achieved": tot_fl / tot_ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
                 "launches_per_step": tot_n / args.steps, "avg_launch_us": 1e3 * tot_ms / tot_n,
                 "gflop_per_launch": tot_fl / tot_n / 1e9, "gemm_ms_per_step": tot_ms / args.steps,
                 "variants": [

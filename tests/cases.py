@@ -11,7 +11,7 @@ def tiny_whisper_config(**kw):
 def tiny_wavlm_config(stable, **kw):
     cfg = synth.base_config("wavlm", wavlm_model="local/wavlm-tinytest", **kw)
     cfg["model"]["encoder_arch"] = dict(
-        d_model=64, layers=2, heads=4, ffn=128, conv_dim=(32,) * 7,
+        d_model=64, layers=2, heads=2, ffn=128, conv_dim=(32,) * 7,
         feat_extract_norm="layer" if stable else "group", conv_bias=stable, stable_layer_norm=stable,
         pos_conv_kernel=16, pos_conv_groups=4, do_normalize=stable)
     return cfg

@@ -58,7 +58,8 @@ torch.set_grad_enabled(False)
 def build_reference(config, labels, tmp):
     """Reference BIOPhonemeTagger over a locally saved random-init HF encoder of the right dims."""
     enc, arch = resolve_encoder_arch(config["model"])
-    d = os.path.join(tmp, f"hf_{enc}_{arch.d_model}_{arch.layers}")
+    tag = getattr(arch, "feat_extract_norm", "")
+    d = os.path.join(tmp, f"hf_{enc}_{arch.d_model}_{arch.layers}_{tag}")
     if not os.path.isdir(d):
         if enc == "whisper":
             hc = WhisperConfig(d_model=arch.d_model, encoder_layers=arch.layers, encoder_attention_heads=arch.heads,
@@ -159,7 +160,7 @@ def tiny_whisper_config(**kw):
 def tiny_wavlm_config(stable, **kw):
     cfg = synth.base_config("wavlm", wavlm_model="local/wavlm-tinytest", **kw)
     cfg["model"]["encoder_arch"] = dict(
-        d_model=64, layers=2, heads=4, ffn=128, conv_dim=(32,) * 7,
+        d_model=64, layers=2, heads=2, ffn=128, conv_dim=(32,) * 7,
         feat_extract_norm="layer" if stable else "group", conv_bias=stable, stable_layer_norm=stable,
         pos_conv_kernel=16, pos_conv_groups=4, do_normalize=stable)
     return cfg

@@ -259,6 +259,26 @@ def test_bilstm_base_matches_reference_golden(golden_dir):
     assert bool(torch.isfinite(big.logits).all())
 
 
+@pytest.mark.parametrize("name", ["wavlm_tiny_group", "wavlm_tiny_stable", "wavlm_base_cfg1"])
+def test_wavlm_matches_reference_golden(name, golden_dir):
+    """WavLM encoder (group-norm / post-LN and layer-norm / stable-pre-LN topologies; BASELINE config 1 = WavLM-base
+    dims + linear head on a 1 s 440 Hz sine) against full tensors recorded from the reference."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = GOLDEN_CASES[name]()
+    m, labels, sd_np = _build(cfg, int(g["n_phonemes"]), int(g["seed"]))
+    B, L = len(g["lang_id"]), int(g["L"])
+    wav = np.stack([synth.sine_clip(L)] * B) if name == "wavlm_base_cfg1" else synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
+    out = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True, want_hidden=True)
+    m.check(B, L)
+    assert tuple(out.logits.shape) == g["logits"].shape
+    h_err = np.abs(out.hidden.cpu().numpy() - g["hidden"])
+    _note("wavlm_hidden_" + name, max=h_err.max(), mean=h_err.mean(), ref_abs_mean=np.abs(g["hidden"]).mean())
+    assert h_err.max() <= 0.15 and h_err.mean() <= 0.02
+    _check_decisions(name, out, torch.from_numpy(g["logits"]), torch.from_numpy(g["offsets"]), labels.index("O"), 0.5)
+    again = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True)
+    assert torch.equal(again.logits, out.logits)
+
+
 def test_graph_replay_is_bit_identical():
     cfg = _tiny()
     m, labels, _ = _build(cfg, 5, seed=24)

@@ -22,7 +22,7 @@ static __device__ __forceinline__ int k_swz(int row) {
   return (row >> 2) & 3;                      // CPR == 4
 }
 
-template <int HD, int QT, bool PREFETCH>
+template <int HD, int QT, bool PREFETCH, bool BIAS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                       // [KT][HD] bf16, 16-byte chunks XOR-swizzled
@@ -35,8 +35,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (4 * QT * 16) + wid * (QT * 16);
+  // XCD-aware order: blocks i and i+8 share an XCD (and its L2).  All query blocks of one (clip, head) read the
+  // same K / V^T, so give each XCD a contiguous run of logical blocks ordered (clip, head, query block): K/V are
+  // then fetched from HBM once per (clip, head) instead of once per XCD (PMC: 419 MB -> algorithmic 74 MB per launch).
+  const int nqb = (p.T + 4 * QT * 16 - 1) / (4 * QT * 16);
+  const int nblk = nqb * p.heads * p.B;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int qb = bid % nqb;
+  const int bh = bid / nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = qb * (4 * QT * 16) + wid * (QT * 16);
   const long row0 = p.lead + (long)b * p.P;
   const bf16_t* Kg = p.QK + p.d + h * HD;                 // + row * ldqk
   const bf16_t* Vg = p.Vt + ((long)b * p.d + h * HD) * p.P;
@@ -120,6 +132,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           st[qt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kk], 0, 0, 0);
+      }
+    }
+    if (BIAS) {
+      // WavLM gated relative position bias (HF modeling_wavlm.py:167-180, 243-271): score += gate[b,h,q] * table[h][k-q],
+      // table = rel_attn_embed[bucket(k - q)][h] * log2(e), one row of 2T-1 entries per head, built at load time
+      const float* tab = p.bias + (long)h * (2 * p.T - 1) + (p.T - 1);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        int q = q0 + qt * 16 + c;
+        q = q < p.T ? q : p.T - 1;
+        const float gq = p.gate[((long)b * p.heads + h) * p.T + q];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int key = kt * KT + kk * 16 + g * 4 + e;
+            key = key < p.T ? key : p.T - 1;
+            st[qt][kk][e] = fmaf(gq, tab[key - q], st[qt][kk][e]);
+          }
       }
     }
     if (kt * KT + KT > p.T) {            // last tile: keys >= T do not exist
@@ -208,17 +239,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 }
 
-template <int HD, int QT, bool PREFETCH>
+template <int HD, int QT, bool PREFETCH, bool BIAS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = KT * HD * 2 + HD * VPITCH;
-  auto k = attn_kernel<HD, QT, PREFETCH>;
+  auto k = attn_kernel<HD, QT, PREFETCH, BIAS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
     attr_set = true;
   }
   const int qb = 4 * QT * 16;
-  dim3 grid((a.T + qb - 1) / qb, a.heads, a.B);
+  dim3 grid(((a.T + qb - 1) / qb) * a.heads * a.B);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -226,11 +257,19 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldo % 4 || a.T <= 0) return -1;
   const int hd = a.d / a.heads;
+  if (a.bias) {
+    if (!a.gate) return -1;
+    switch (hd) {
+      case 32: return launch_attn<32, 2, true, true>(a, s);
+      case 64: return launch_attn<64, 2, true, true>(a, s);
+    }
+    return -4;
+  }
   switch (hd) {
-    case 32: return launch_attn<32, 2, true>(a, s);
-    case 64: return launch_attn<64, 2, true>(a, s);
-    case 128: return launch_attn<128, 2, true>(a, s);
-    case 256: return launch_attn<256, 1, false>(a, s);
+    case 32: return launch_attn<32, 2, true, false>(a, s);
+    case 64: return launch_attn<64, 2, true, false>(a, s);
+    case 128: return launch_attn<128, 2, true, false>(a, s);
+    case 256: return launch_attn<256, 1, false, false>(a, s);
   }
   return -4;   // unsupported head_dim
 }

@@ -53,6 +53,25 @@ struct LstmArgs {
   unsigned* error;
 };
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s);
+
+struct Conv0Args {
+  const float* wav; long ldw; int L;
+  const double* wstats;
+  const float* w;
+  const float* bias;
+  const float* gamma; const float* beta;
+  int B, T0, C;
+  double* cstats;
+  bf16_t* out; long lead; int P;
+};
+int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s);
+int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s);
+int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s);
+int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
+                           const float* b8, const float* cst, float* gate, hipStream_t s);
+int wfl_launch_relpos_table(const float* rel_emb, const int* bucket_of_delta, int max_t, int heads, int T, float* table, hipStream_t s);
+int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
+                             int B, int P, int T, int C, int gelu, hipStream_t s);
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
@@ -79,6 +98,7 @@ static inline uint16_t f32_to_bf16_bits(float f) {
 }
 
 static inline long round_up(long x, long m) { return (x + m - 1) / m * m; }
+#define WAVLM_MAX_T 4096   // frames per clip the relative-position bucket table covers (81 s of audio)
 
 struct HostTensor {
   std::vector<int64_t> shape;
@@ -95,6 +115,7 @@ struct Lin {
 struct LNp { float* g = nullptr; float* b = nullptr; };
 
 struct EncLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2; };
+struct WavlmLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2; float *w8 = nullptr, *b8 = nullptr, *cst = nullptr; };
 struct ConfLayer {
   LNp ff1_ln, ff2_ln, ln1, ln2;
   Lin ff1_a, ff1_b, ff2_a, ff2_b, qkv, out, pw1, conv, pw2;
@@ -123,6 +144,18 @@ struct wfl_model {
   bf16_t* pos = nullptr;
   std::vector<EncLayer> enc;
   LNp enc_ln;
+  // wavlm
+  float *conv0_w = nullptr, *conv0_b = nullptr;
+  LNp conv0_norm;
+  std::vector<Lin> fconv;            // feature-encoder layers 1..n-1 as GEMMs
+  std::vector<LNp> fconv_ln;         // "layer" checkpoints: LayerNorm after every conv
+  LNp fp_ln;
+  Lin fp_proj;
+  std::vector<Lin> posconv;          // one GEMM per group over [rows][64]-regrouped channels
+  LNp wenc_ln;
+  std::vector<WavlmLayer> wl;
+  float* rel_emb = nullptr;          // [num_buckets][heads]
+  int* bucket_of_delta = nullptr;    // [2*WAVLM_MAX_T - 1]
   // head
   Lin lang;
   float* lang_table = nullptr;    // [num_languages][d]
@@ -159,6 +192,23 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (a.n_conformer > 0) pad = std::max(pad, a.conformer_kernel / 2);
   if (a.enable_dilated)
     for (int i = 0; i < a.dilated_depth; ++i) pad = std::max(pad, (1 << i) * (a.dilated_kernel - 1) / 2);
+  if (a.encoder_type == WFL_ENC_WAVLM) {
+    if (a.wavlm_n_conv < 2 || a.wavlm_n_conv > 8 || a.wavlm_conv_kernel[0] != 10 || a.wavlm_conv_stride[0] != 5) {
+      delete m;
+      return fail(-1, "WavLM feature encoder: layer 0 must be k=10 s=5 (all released checkpoints)");
+    }
+    for (int i = 1; i < a.wavlm_n_conv; ++i)
+      if (a.wavlm_conv_stride[i] != 2 || a.wavlm_conv_dim[i] != a.wavlm_conv_dim[0] || a.wavlm_conv_dim[i] % 8 || a.wavlm_conv_dim[i] > 512) {
+        delete m;
+        return fail(-1, "WavLM feature encoder: layers 1.. must be stride 2 with one common width <= 512");
+      }
+    if (a.wavlm_pos_conv_kernel % 2 || a.d_model % a.wavlm_pos_conv_groups || a.d_model / a.wavlm_pos_conv_groups > 64 ||
+        (a.d_model / a.wavlm_pos_conv_groups) % 8) {
+      delete m;
+      return fail(-1, "WavLM positional conv: even kernel and d_model/groups a multiple of 8, <= 64");
+    }
+    pad = std::max(pad, a.wavlm_pos_conv_kernel / 2);
+  }
   m->halo = (int)round_up(pad + 1, 8);
   *out = m;
   return 0;
@@ -368,6 +418,107 @@ static int finalize_whisper(wfl_model* m, Packer& P) {
   return 0;
 }
 
+static int finalize_wavlm(wfl_model* m, Packer& P) {
+  const wfl_arch& a = m->a;
+  const int d = a.d_model, hd = d / a.enc_heads, C = a.wavlm_conv_dim[0], nconv = a.wavlm_n_conv;
+  const bool group = a.wavlm_group_norm != 0, cbias = a.wavlm_conv_bias != 0;
+  const std::string fe = "encoder.feature_extractor.conv_layers.";
+  if (const HostTensor* w0 = P.get(fe + "0.conv.weight", {C, 1, 10})) m->conv0_w = P.upload(w0->data);
+  if (cbias)
+    if (const HostTensor* b0 = P.get(fe + "0.conv.bias", {C})) m->conv0_b = P.upload(b0->data);
+  m->conv0_norm = P.ln(fe + "0.layer_norm", C);
+  for (int i = 1; i < nconv; ++i) {
+    m->fconv.push_back(P.conv(fe + std::to_string(i) + ".conv", C, C, a.wavlm_conv_kernel[i], nullptr, nullptr, cbias));
+    if (!group) m->fconv_ln.push_back(P.ln(fe + std::to_string(i) + ".layer_norm", C));
+  }
+  m->fp_ln = P.ln("encoder.feature_projection.layer_norm", C);
+  m->fp_proj = P.linear("encoder.feature_projection.projection", d, C);
+  // positional conv: weight = g * v / ||v||, norm over dims (0, 1) per tap (weight_norm dim=2); HF modeling_wavlm.py:48-90
+  {
+    const int G = a.wavlm_pos_conv_groups, cpg = d / G, K = a.wavlm_pos_conv_kernel;
+    const std::string pc = "encoder.encoder.pos_conv_embed.conv.";
+    const HostTensor* g0 = P.get(pc + "parametrizations.weight.original0", {1, 1, K});
+    const HostTensor* v = P.get(pc + "parametrizations.weight.original1", {d, cpg, K});
+    const HostTensor* pb = P.get(pc + "bias", {d});
+    if (g0 && v && pb) {
+      std::vector<double> nrm(K, 0.0);
+      for (int o = 0; o < d; ++o)
+        for (int c = 0; c < cpg; ++c)
+          for (int k = 0; k < K; ++k) { const double x = v->data[((size_t)o * cpg + c) * K + k]; nrm[k] += x * x; }
+      for (int k = 0; k < K; ++k) nrm[k] = std::sqrt(nrm[k]);
+      for (int gi = 0; gi < G; ++gi) {
+        // rows = the group's cpg output channels, k index = tap * 64 + channel (channels padded to 64)
+        std::vector<float> rows((size_t)cpg * K * 64, 0.f), bias(cpg);
+        for (int o = 0; o < cpg; ++o) {
+          const int oc = gi * cpg + o;
+          bias[o] = pb->data[oc];
+          for (int c = 0; c < cpg; ++c)
+            for (int k = 0; k < K; ++k)
+              rows[((size_t)o * K + k) * 64 + c] = (float)(g0->data[k] * v->data[((size_t)oc * cpg + c) * K + k] / nrm[k]);
+        }
+        m->posconv.push_back(P.pack(rows, cpg, K * 64, &bias));
+      }
+    }
+  }
+  m->wenc_ln = P.ln("encoder.encoder.layer_norm", d);
+  const float qs = (float)(std::pow((double)hd, -0.5) * 1.4426950408889634);
+  m->wl.resize(a.enc_layers);
+  for (int i = 0; i < a.enc_layers; ++i) {
+    const std::string p = "encoder.encoder.layers." + std::to_string(i) + ".";
+    WavlmLayer& L = m->wl[i];
+    L.ln1 = P.ln(p + "layer_norm", d);
+    L.ln2 = P.ln(p + "final_layer_norm", d);
+    const HostTensor* wq = P.get(p + "attention.q_proj.weight", {d, d});
+    const HostTensor* bq = P.get(p + "attention.q_proj.bias", {d});
+    const HostTensor* wk = P.get(p + "attention.k_proj.weight", {d, d});
+    const HostTensor* bk = P.get(p + "attention.k_proj.bias", {d});
+    const HostTensor* wv = P.get(p + "attention.v_proj.weight", {d, d});
+    const HostTensor* bv = P.get(p + "attention.v_proj.bias", {d});
+    if (wq && bq && wk && bk && wv && bv) {
+      std::vector<float> rows((size_t)3 * d * d), bias((size_t)3 * d);
+      for (size_t j = 0; j < (size_t)d * d; ++j) {
+        rows[j] = wq->data[j] * qs;
+        rows[(size_t)d * d + j] = wk->data[j];
+        rows[(size_t)2 * d * d + j] = wv->data[j];
+      }
+      for (int j = 0; j < d; ++j) { bias[j] = bq->data[j] * qs; bias[d + j] = bk->data[j]; bias[2 * d + j] = bv->data[j]; }
+      L.qkv = P.pack(rows, 3 * d, d, &bias);
+    }
+    L.out = P.linear(p + "attention.out_proj", d, d);
+    L.fc1 = P.linear(p + "feed_forward.intermediate_dense", a.enc_ffn, d);
+    L.fc2 = P.linear(p + "feed_forward.output_dense", d, a.enc_ffn);
+    if (const HostTensor* w8 = P.get(p + "attention.gru_rel_pos_linear.weight", {8, hd})) L.w8 = P.upload(w8->data);
+    if (const HostTensor* b8 = P.get(p + "attention.gru_rel_pos_linear.bias", {8})) L.b8 = P.upload(b8->data);
+    if (const HostTensor* cst = P.get(p + "attention.gru_rel_pos_const", {1, a.enc_heads, 1, 1})) L.cst = P.upload(cst->data);
+    if (i == 0) {
+      if (const HostTensor* re = P.get(p + "attention.rel_attn_embed.weight", {a.wavlm_num_buckets, a.enc_heads})) {
+        std::vector<float> scaled(re->data);
+        for (auto& x : scaled) x *= 1.4426950408889634f;           // scores live in the log2 domain
+        m->rel_emb = P.upload(scaled);
+      }
+    }
+  }
+  // relative-position buckets (HF modeling_wavlm.py:243-271), float32 arithmetic like torch
+  {
+    std::vector<int> bod(2 * WAVLM_MAX_T - 1);
+    const int nb = a.wavlm_num_buckets / 2, max_exact = nb / 2;
+    for (int delta = -(WAVLM_MAX_T - 1); delta <= WAVLM_MAX_T - 1; ++delta) {
+      int bkt = delta > 0 ? nb : 0;
+      const int ad = delta < 0 ? -delta : delta;
+      if (ad < max_exact) bkt += ad;
+      else {
+        const float v = std::log((float)ad / (float)max_exact) / (float)std::log((double)a.wavlm_max_distance / max_exact) * (float)(nb - max_exact);
+        int large = max_exact + (int)v;
+        if (large > nb - 1) large = nb - 1;
+        bkt += large;
+      }
+      bod[delta + WAVLM_MAX_T - 1] = bkt;
+    }
+    m->bucket_of_delta = P.upload(bod);
+  }
+  return 0;
+}
+
 static int finalize_head(wfl_model* m, Packer& P) {
   const wfl_arch& a = m->a;
   const int d = a.d_model, e = a.lang_emb_dim;
@@ -499,7 +650,7 @@ int32_t wfl_finalize(wfl_model* m) {
   if (m->finalized) return fail(-1, "wfl_finalize: already finalized");
   Packer P{m};
   if (m->a.encoder_type == WFL_ENC_WHISPER) finalize_whisper(m, P);
-  else P.err = "WavLM encoder is not built into this library yet";
+  else finalize_wavlm(m, P);
   if (P.err.empty()) finalize_head(m, P);
   if (!P.err.empty()) return fail(-2, "wfl_finalize: " + P.err);
   for (auto& kv : m->host)
@@ -517,15 +668,29 @@ struct Plan {
   int T2, P2, lead2;            // whisper stem input rows (mel frames)
   long R, R2;
   int d, ffw;
+  // wavlm feature-encoder levels: level i = output of conv layer i (frames T_i, pitch P_i = P * 2^(n-1-i), lead 8)
+  int nlev, Tl[8], Pl[8], leadl[8];
+  long Rl[8];
   // byte offsets
-  long mel, c1, X, Y, ATT, QK, VT, FF, raw, clipmax, logits, logits2, offs2, gx, lstm_x, total;
+  long mel, c1, X, Y, ATT, QK, VT, FF, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
+  long FA, FB, XG, gate, rtab, wstats, cstats, total;
 };
+
+static int wavlm_frames(const wfl_arch& a, int L) {
+  long t = L;
+  for (int i = 0; i < a.wavlm_n_conv; ++i) {
+    if (t < a.wavlm_conv_kernel[i]) return 0;
+    t = (t - a.wavlm_conv_kernel[i]) / a.wavlm_conv_stride[i] + 1;
+  }
+  return (int)t;
+}
 
 static Plan make_plan(const wfl_model* m, int B, int L) {
   const wfl_arch& a = m->a;
+  const bool whisper = a.encoder_type == WFL_ENC_WHISPER;
   Plan p{};
   p.B = B; p.L = L;
-  p.T = a.max_positions;
+  p.T = whisper ? a.max_positions : wavlm_frames(a, L);
   p.P = (int)round_up(p.T + m->halo, 8);
   p.lead = m->halo;
   p.tail = 256;
@@ -536,15 +701,38 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
   p.ffw = std::max(a.enc_ffn, a.d_model * std::max(a.conformer_ff_expansion, 1));
   long off = 0;
   auto take = [&](long bytes) { long o = off; off = round_up(off + bytes, 256); return o; };
-  p.mel = take(p.R2 * a.n_mels * 2 + 1024);
-  p.c1 = take(p.R2 * p.d * 2);
+  if (whisper) {
+    p.mel = take(p.R2 * a.n_mels * 2 + 1024);
+    p.c1 = take(p.R2 * p.d * 2);
+    p.raw = take((long)B * p.T2 * a.n_mels * 4);
+  } else {
+    const int n = a.wavlm_n_conv, C = a.wavlm_conv_dim[0];
+    p.nlev = n;
+    long t = L;
+    for (int i = 0; i < n; ++i) {
+      t = t >= a.wavlm_conv_kernel[i] ? (t - a.wavlm_conv_kernel[i]) / a.wavlm_conv_stride[i] + 1 : 0;
+      p.Tl[i] = (int)t;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      p.Pl[i] = i == n - 1 ? p.P : p.Pl[i + 1] * 2;
+      p.leadl[i] = i == n - 1 ? p.lead : 8;
+      p.Rl[i] = p.leadl[i] + (long)B * p.Pl[i] + p.tail;
+    }
+    p.FA = take(p.Rl[0] * C * 2);                     // levels 0, 2, 4, 6
+    p.FB = take(p.Rl[1] * C * 2);                     // levels 1, 3, 5
+    p.XG = take((long)a.wavlm_pos_conv_groups * p.R * 64 * 2);
+    p.gate = take((long)B * a.enc_heads * p.T * 4);
+    p.rtab = take((long)a.enc_heads * (2L * p.T + 1) * 4);
+    p.wstats = take((long)B * 2 * 8);
+    p.cstats = take((long)B * C * 2 * 8);
+  }
   p.X = take(p.R * p.d * 2);
   p.Y = take(p.R * p.d * 2);
   p.ATT = take(p.R * p.d * 2);
   p.QK = take(p.R * 2 * p.d * 2);
   p.VT = take(((long)B * p.d * p.P + 256) * 2);
   p.FF = take(p.R * p.ffw * 2);
-  p.raw = take((long)B * p.T2 * a.n_mels * 4);
+  p.enc2 = take(p.R * p.d * 2);
   p.clipmax = take((long)B * 4);
   p.logits = take((long)B * p.T * a.num_classes * 4);
   p.logits2 = take((long)B * p.T * a.num_classes * 4);
@@ -562,8 +750,7 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
 
 int32_t wfl_num_frames(const wfl_model* m, int32_t L) {
   if (!m) return -1;
-  (void)L;
-  return m->a.max_positions;
+  return m->a.encoder_type == WFL_ENC_WHISPER ? m->a.max_positions : wavlm_frames(m->a, L);
 }
 
 int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L) {
@@ -628,9 +815,10 @@ struct Runner {
     if (r) rc = fail(r, "layernorm launch failed");
   }
 
-  void attn(int heads) {
+  void attn(int heads, const float* bias = nullptr, const float* gate = nullptr) {
     if (rc) return;
     AttnArgs a{};
+    a.bias = bias; a.gate = gate;
     a.QK = buf(p.QK); a.ldqk = 2 * p.d; a.lead = p.lead; a.Vt = buf(p.VT); a.O = buf(p.ATT); a.ldo = p.d;
     a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = p.d;
     const int r = wfl_launch_attention(a, s);
@@ -639,7 +827,8 @@ struct Runner {
 
   void zero(long off, long ld_elems, long lead, int P, int T, long tail) {
     if (rc) return;
-    const int r = wfl_launch_zero_halo(buf(off), ld_elems * 2, lead, p.B, P, T, tail, s);
+    // `tail` = rows behind the last clip's pitch; the kernel counts from the last clip's last valid frame
+    const int r = wfl_launch_zero_halo(buf(off), ld_elems * 2, lead, p.B, P, T, (long)(P - T) + tail, s);
     if (r) rc = fail(r, "zero_halo launch failed");
   }
 };
@@ -684,9 +873,8 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
   const long Mrows = (long)B * p.P;
   bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *VT = R.buf(p.VT), *FF = R.buf(p.FF);
 
+  if (p.T <= 0) return fail(-1, "wfl_forward: clip too short for the encoder");
   // halos of every frame-row buffer (cheap; keeps the layout invariant independent of the workspace's history)
-  R.zero(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
-  R.zero(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
   R.zero(p.X, d, p.lead, p.P, p.T, p.tail);
   R.zero(p.Y, d, p.lead, p.P, p.T, p.tail);
   R.zero(p.ATT, d, p.lead, p.P, p.T, p.tail);
@@ -694,8 +882,11 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
   R.zero(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
   if (R.rc) return R.rc;
 
-  // ---- Whisper encoder (HF modeling_whisper.py:618-642)
-  {
+  if (a.encoder_type == WFL_ENC_WHISPER) {
+    // ---- Whisper encoder (HF modeling_whisper.py:618-642)
+    R.zero(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
+    R.zero(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
+    if (R.rc) return R.rc;
     const int r = run_logmel(m, p, R.ws, wav, ldw, lens, nullptr, R.s);
     if (r) return fail(r, "logmel launch failed");
     bf16_t* mel = R.buf(p.mel);
@@ -717,6 +908,101 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
     }
     R.ln(X, Y, m->enc_ln);       // encoder output in Y
+  } else {
+    // ---- WavLM (HF modeling_wavlm.py:1032-1088).  `lens` is not supported: the reference never pads WavLM input.
+    if (lens) return fail(-1, "wfl_forward: per-clip lengths are not supported with the WavLM encoder (batch clips of equal length)");
+    if (p.T > WAVLM_MAX_T) return fail(-1, "wfl_forward: clip too long for the WavLM relative-position table");
+    const int C = a.wavlm_conv_dim[0], n = p.nlev;
+    bf16_t* F[2] = {R.buf(p.FA), R.buf(p.FB)};
+    double* wstats = nullptr;
+    if (a.wavlm_do_normalize) {
+      wstats = (double*)(R.ws + p.wstats);
+      const int r = wfl_launch_wav_stats(wav, ldw, B, L, wstats, R.s);
+      if (r) return fail(r, "wav_stats launch failed");
+    }
+    // Rows that are not valid frames of a level are zeroed before the level is produced (the two buffers alternate
+    // between levels; a K-padded conv GEMM may read a few channels past the last valid frame).
+    R.zero(p.FA, C, p.leadl[0], p.Pl[0], p.Tl[0], p.tail);
+    if (R.rc) return R.rc;
+    {
+      Conv0Args c{};
+      c.wav = wav; c.ldw = ldw; c.L = L; c.wstats = wstats; c.w = m->conv0_w; c.bias = m->conv0_b;
+      c.gamma = m->conv0_norm.g; c.beta = m->conv0_norm.b; c.B = B; c.T0 = p.Tl[0]; c.C = C;
+      c.cstats = (double*)(R.ws + p.cstats); c.out = F[0]; c.lead = p.leadl[0]; c.P = p.Pl[0];
+      const int r = wfl_launch_conv0(c, a.wavlm_group_norm, R.s);
+      if (r) return fail(r, "conv0 launch failed");
+    }
+    for (int i = 1; i < n; ++i) {
+      // conv k, stride 2, no padding: output frame t reads input rows 2t .. 2t+k-1 = k*C contiguous channels, lda = 2C
+      const bf16_t* in = F[(i - 1) & 1] + (long)p.leadl[i - 1] * C;
+      bf16_t* out = F[i & 1];
+      const bool group = a.wavlm_group_norm != 0;
+      R.zero((i & 1) ? p.FB : p.FA, C, p.leadl[i], p.Pl[i], p.Tl[i], p.tail);
+      R.gemm(in, 2 * C, m->fconv[i - 1], B * p.Pl[i], p.Pl[i], p.Tl[i], out, C, p.leadl[i], p.Pl[i], group ? WFL_ACT_GELU : WFL_ACT_NONE);
+      if (!group && !R.rc) {
+        const int r = wfl_launch_layernorm_act(out, C, out, C, m->fconv_ln[i - 1].g, m->fconv_ln[i - 1].b, 1e-5f, p.leadl[i], B,
+                                               p.Pl[i], p.Tl[i], C, 1, R.s);
+        if (r) return fail(r, "layernorm launch failed");
+      }
+    }
+    if (R.rc) return R.rc;
+    bf16_t* feats = F[(n - 1) & 1];                    // level n-1 has the main geometry (lead, P, T)
+    {
+      const int r = wfl_launch_layernorm_act(feats, C, feats, C, m->fp_ln.g, m->fp_ln.b, 1e-5f, p.lead, B, p.P, p.T, C, 0, R.s);
+      if (r) return fail(r, "layernorm launch failed");
+    }
+    R.gemm(feats + (long)p.lead * C, C, m->fp_proj, (int)Mrows, p.P, p.T, X, d, p.lead, p.P);
+    // positional conv: x + GELU(grouped conv k, pad k/2, last step dropped), one contiguous-tap GEMM per group
+    {
+      const int G = a.wavlm_pos_conv_groups, cpg = d / G, K = a.wavlm_pos_conv_kernel;
+      bf16_t* XG = R.buf(p.XG);
+      if (!R.rc) {
+        const int r = wfl_launch_regroup(X, d, G, cpg, p.R, p.lead, B, p.P, p.T, XG, R.s);
+        if (r) return fail(r, "regroup launch failed");
+      }
+      for (int gi = 0; gi < G; ++gi)
+        R.gemm(XG + ((long)gi * p.R + p.lead - K / 2) * 64, 64, m->posconv[gi], (int)Mrows, p.P, p.T, Y + gi * cpg, d, p.lead, p.P,
+               WFL_ACT_GELU, X + gi * cpg, d, 1.f);
+    }
+    bf16_t *H = Y, *S = X;                             // current hidden states / scratch
+    const bool stable = a.wavlm_stable_layer_norm != 0;
+    if (!stable) { R.ln(H, S, m->wenc_ln); std::swap(H, S); }
+    float* gate = (float*)(R.ws + p.gate);
+    float* rtab = (float*)(R.ws + p.rtab);
+    if (!R.rc) {
+      const int r = wfl_launch_relpos_table(m->rel_emb, m->bucket_of_delta, WAVLM_MAX_T, a.enc_heads, p.T, rtab, R.s);
+      if (r) return fail(r, "relpos_table launch failed");
+    }
+    const int hd = d / a.enc_heads;
+    for (int i = 0; i < a.enc_layers && !R.rc; ++i) {
+      const WavlmLayer& L_ = m->wl[i];
+      bf16_t* A_in = H;                                // what the attention block sees
+      if (stable) { R.ln(H, S, L_.ln1); A_in = S; }
+      if (R.rc) break;
+      int r = wfl_launch_relpos_gate(A_in, d, p.lead, B, p.P, p.T, a.enc_heads, hd, L_.w8, L_.b8, L_.cst, gate, R.s);
+      if (r) return fail(r, "relpos_gate launch failed");
+      R.gemm(A_in + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 2 * d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
+             false, false, VT, 2 * d);
+      R.attn(a.enc_heads, rtab, gate);
+      if (stable) {
+        // x = x + attn; x = x + FFN(LN(x))
+        R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+        R.ln(H, S, L_.ln2);
+        R.gemm(S + (long)p.lead * d, d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+        R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+      } else {
+        // x = LN(x + attn); x = LN_final(x + FFN(x))
+        R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+        R.ln(S, H, L_.ln1);
+        R.gemm(H + (long)p.lead * d, d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+        R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+        R.ln(S, H, L_.ln2);
+      }
+    }
+    if (stable) { R.ln(H, S, m->wenc_ln); std::swap(H, S); }
+    if (H != Y && !R.rc) {                             // the head expects the encoder output in Y
+      HIPCHK(hipMemcpyAsync(Y, H, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
+    }
   }
   if (R.rc) return R.rc;
   if (hidden) {
@@ -730,8 +1016,8 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
   bf16_t* ENC = Y;
   // the head needs Y as scratch: keep the encoder output in ATT when more than one pass reads it
   if (n_pass > 1) {
-    HIPCHK(hipMemcpyAsync(R.buf(p.c1), Y, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
-    ENC = R.buf(p.c1);
+    HIPCHK(hipMemcpyAsync(R.buf(p.enc2), Y, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
+    ENC = R.buf(p.enc2);
   }
   int* lang_dev = nullptr;
   for (int pass = 0; pass < n_pass; ++pass) {

@@ -5,7 +5,7 @@
 
 // One wave per frame row, 8 channels (16 bytes) per lane per step, statistics in fp32 (mean, then centred
 // variance, as torch does), biased variance, eps inside the rsqrt.
-template <int NCH>   // 16-byte chunks per lane (C <= NCH * 512)
+template <int NCH, bool GELU>   // 16-byte chunks per lane (C <= NCH * 512); GELU: exact-erf GELU after the affine
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                         long ldy, const float* __restrict__ gam,
                                                         const float* __restrict__ bet, float eps, long lead, int B, int P,
@@ -55,26 +55,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = f2bf((v[i][e] - mean) * rstd * g0[e] + b0[e]);
-        o[4 + e] = f2bf((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+        float y0 = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+        float y1 = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+        if (GELU) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); }
+        o[e] = f2bf(y0);
+        o[4 + e] = f2bf(y1);
       }
       *(bf16x8*)(yp + c0) = o;
     }
   }
 }
 
-int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
-                         long lead, int B, int P, int T, int C, hipStream_t s) {
-  if (C % 8 || ldx % 8 || ldy % 8 || C > 2048) return -1;
+template <bool GELU>
+static int launch_ln(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead, int B,
+                     int P, int T, int C, hipStream_t s) {
   const long rows = (long)B * T;
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (C <= 512)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
   else if (C <= 1024)
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
   else
-    hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
+                             int B, int P, int T, int C, int gelu, hipStream_t s) {
+  if (C % 8 || ldx % 8 || ldy % 8 || C > 2048) return -1;
+  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s)
+              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s);
+}
+
+int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
+                         long lead, int B, int P, int T, int C, hipStream_t s) {
+  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s);
 }
 
 // Zero every row that is not a valid frame: [0, lead), each clip's [T, P), and `tail_rows` rows behind the last

@@ -1,0 +1,269 @@
+// WavLM-specific kernels (the rest of the WavLM encoder reuses gemm / attention / layernorm):
+//   * waveform statistics for Wav2Vec2FeatureExtractor's do_normalize   (HF feature_extraction_wav2vec2.py:78-97)
+//   * conv layer 0 of the feature encoder (Cin = 1, k = 10, stride 5) fused with its normalisation + GELU:
+//       "group" checkpoints (base / base-plus): GroupNorm(C groups) = per-channel statistics over ALL time steps
+//          of a clip -> pass 1 accumulates sum / sum-of-squares per (clip, channel) in fp64 atomics WITHOUT storing
+//          the 98 MB/clip activation, pass 2 recomputes the 10-tap conv (10 MACs) and writes GELU(GN(y)) once;
+//       "layer" checkpoints (large): conv + bias -> LayerNorm over channels -> GELU, one wave per time step.
+//     (HF modeling_wavlm.py:675-744, 772-782)
+//   * channel regrouping for the grouped positional conv (HF modeling_wavlm.py:48-90): [rows][d] -> [groups][rows][64]
+//     so each group's k=128 conv becomes a contiguous-tap GEMM
+//   * the gated relative-position-bias gate (HF modeling_wavlm.py:167-180)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- waveform statistics
+__global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, long ldw, int L, double* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const float* w = wav + (long)b * ldw;
+  double s = 0.0, q = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+    const double v = w[i];
+    s += v;
+    q += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 2 * b, s); atomicAdd(stats + 2 * b + 1, q); }
+}
+
+struct Conv0Args {
+  const float* wav; long ldw; int L;      // [B][ldw]
+  const double* wstats;                   // [B][2] sum, sumsq of the waveform, or null (do_normalize off)
+  const float* w;                         // [C][10]
+  const float* bias;                      // [C] or null
+  const float* gamma; const float* beta;  // [C]
+  int B, T0, C;
+  double* cstats;                         // [B][C][2] (group mode)
+  bf16_t* out; long lead; int P;          // frame rows [.., C]
+};
+
+static __device__ __forceinline__ void wav_norm(const Conv0Args& p, int b, float& mean, float& rstd) {
+  mean = 0.f; rstd = 1.f;
+  if (p.wstats) {
+    const double m = p.wstats[2 * b] / p.L;
+    const double var = p.wstats[2 * b + 1] / p.L - m * m;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-7));
+  }
+}
+
+#define C0_TT 512          // time steps per workgroup
+template <bool APPLY>
+__global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
+  __shared__ float xs[C0_TT * 5 + 16];
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
+  const int nt = min(C0_TT, p.T0 - t0);
+  float mean, rstd;
+  wav_norm(p, b, mean, rstd);
+  const float* w = p.wav + (long)b * p.ldw;
+  for (int i = threadIdx.x; i < nt * 5 + 5; i += 256) {
+    const long s = (long)t0 * 5 + i;
+    xs[i] = s < p.L ? (w[s] - mean) * rstd : 0.f;
+  }
+  __syncthreads();
+  for (int c0 = threadIdx.x * 2; c0 < p.C; c0 += 512) {
+    float wa[10], wb[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { wa[j] = p.w[c0 * 10 + j]; wb[j] = p.w[(c0 + 1) * 10 + j]; }
+    if (!APPLY) {
+      float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+      for (int t = 0; t < nt; ++t) {
+        float ya = 0.f, yb = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const float x = xs[t * 5 + j]; ya = fmaf(wa[j], x, ya); yb = fmaf(wb[j], x, yb); }
+        sa += ya; qa += ya * ya; sb += yb; qb += yb * yb;
+      }
+      double* st = p.cstats + ((long)b * p.C + c0) * 2;
+      atomicAdd(st, (double)sa); atomicAdd(st + 1, (double)qa);
+      atomicAdd(st + 2, (double)sb); atomicAdd(st + 3, (double)qb);
+    } else {
+      const double* st = p.cstats + ((long)b * p.C + c0) * 2;
+      const double ma = st[0] / p.T0, mb = st[2] / p.T0;
+      const double va = st[1] / p.T0 - ma * ma, vb = st[3] / p.T0 - mb * mb;
+      const float sca = (float)(1.0 / sqrt((va > 0 ? va : 0) + 1e-5)) * p.gamma[c0];
+      const float scb = (float)(1.0 / sqrt((vb > 0 ? vb : 0) + 1e-5)) * p.gamma[c0 + 1];
+      const float sha = p.beta[c0] - (float)ma * sca, shb = p.beta[c0 + 1] - (float)mb * scb;
+      bf16_t* op = p.out + (p.lead + (long)b * p.P + t0) * p.C + c0;
+      for (int t = 0; t < nt; ++t) {
+        float ya = 0.f, yb = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const float x = xs[t * 5 + j]; ya = fmaf(wa[j], x, ya); yb = fmaf(wb[j], x, yb); }
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 o;
+        o[0] = f2bf(gelu_erf(fmaf(ya, sca, sha)));
+        o[1] = f2bf(gelu_erf(fmaf(yb, scb, shb)));
+        *(bf16x2*)(op + (long)t * p.C) = o;
+      }
+    }
+  }
+}
+
+// "layer" mode: one wave per time step, 8 channels per lane (C <= 512), LayerNorm over channels, GELU
+__global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  float mean, rstd;
+  wav_norm(p, b, mean, rstd);
+  const int c0 = lane * 8;
+  const bool act = c0 < p.C;
+  float wt[8][10], bs[8], gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = act ? c0 + e : 0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wt[e][j] = p.w[c * 10 + j];
+    bs[e] = p.bias ? p.bias[c] : 0.f;
+    gm[e] = p.gamma[c];
+    bt[e] = p.beta[c];
+  }
+  const float* w = p.wav + (long)b * p.ldw;
+  for (int t = blockIdx.x * 4 + wid; t < p.T0; t += gridDim.x * 4) {
+    float x[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const long s = (long)t * 5 + j;
+      x[j] = s < p.L ? (w[s] - mean) * rstd : 0.f;
+    }
+    float y[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = bs[e];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a = fmaf(wt[e][j], x[j], a);
+      y[e] = act ? a : 0.f;
+      sum += y[e];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mu = sum / p.C;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = act ? y[e] - mu : 0.f; sq += d * d; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rs = rsqrtf(sq / p.C + 1e-5f);
+    if (act) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf((y[e] - mu) * rs * gm[e] + bt[e]));
+      *(bf16x8*)(p.out + (p.lead + (long)b * p.P + t) * p.C + c0) = o;
+    }
+  }
+}
+
+int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s) {
+  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s) != hipSuccess) return -3;
+  int blocks = (L + 256 * 16 - 1) / (256 * 16);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(wav_stats_kernel, dim3(blocks, B), dim3(256), 0, s, wav, ldw, L, stats);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s) {
+  if (a.C % 8 || a.C > 512 || a.T0 <= 0) return -1;
+  if (group_norm) {
+    if (hipMemsetAsync(a.cstats, 0, sizeof(double) * 2 * a.B * a.C, s) != hipSuccess) return -3;
+    dim3 grid((a.T0 + C0_TT - 1) / C0_TT, a.B);
+    hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), 0, s, a);
+  } else {
+    int bx = (a.T0 + 3) / 4;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(conv0_layer_kernel, dim3(bx, a.B), dim3(256), 0, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---------------------------------------------------------------------------------------------- positional-conv regroup
+// x [R rows][d] (frame rows) -> xg [groups][R][64]: channels g*cpg .. +cpg of every valid frame, zero elsewhere
+// (padding channels, halo rows): each group's k-tap conv then reads k*64 contiguous elements per frame.
+__global__ __launch_bounds__(256) void regroup_kernel(const bf16_t* __restrict__ x, int d, int groups, int cpg, long R, long lead,
+                                                      int B, int P, int T, bf16_t* __restrict__ xg) {
+  const long total = (long)groups * R * 8;     // 16-byte chunks
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i & 7);
+    const long gr = i >> 3;
+    const long r = gr % R;
+    const int g = (int)(gr / R);
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
+    const long k = r - lead;
+    if (k >= 0 && k < (long)B * P && (k % P) < T) {
+      const int c0 = ch * 8;
+      if (c0 + 8 <= cpg) v = *(const bf16x8*)(x + r * d + g * cpg + c0);
+      else if (c0 < cpg) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (c0 + e < cpg) v[e] = x[r * d + g * cpg + c0 + e];
+      }
+    }
+    *(bf16x8*)(xg + (gr << 6) + ch * 8) = v;
+  }
+}
+
+int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s) {
+  if (cpg > 64 || cpg % 8 || (cpg * groups) != d) return -1;
+  const long total = (long)groups * R * 8;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, d, groups, cpg, R, lead, B, P, T, xg);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---------------------------------------------------------------------------------------------- rel-pos gate
+// gate[b][h][t] = ga * (gb * const_h - 1) + 2,  (ga, gb) = sigmoid( (W8 x_head + b8).view(2, 4).sum(-1) )
+__global__ __launch_bounds__(256) void relpos_gate_kernel(const bf16_t* __restrict__ x, long ldx, long lead, int B, int P, int T,
+                                                          int heads, int hd, const float* __restrict__ w8,
+                                                          const float* __restrict__ b8, const float* __restrict__ cst,
+                                                          float* __restrict__ gate) {
+  const long total = (long)B * T * heads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int h = (int)(i % heads);
+    const long bt = i / heads;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const bf16_t* xp = x + (lead + (long)b * P + t) * ldx + h * hd;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = b8[o];
+    for (int k = 0; k < hd; k += 8) {
+      const bf16x8 v = *(const bf16x8*)(xp + k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xv = bf2f(v[e]);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = fmaf(w8[o * hd + k + e], xv, acc[o]);
+      }
+    }
+    const float ga = sigmoidf_(acc[0] + acc[1] + acc[2] + acc[3]);
+    const float gb = sigmoidf_(acc[4] + acc[5] + acc[6] + acc[7]);
+    gate[((long)b * heads + h) * T + t] = ga * (gb * cst[h] - 1.0f) + 2.0f;
+  }
+}
+
+int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
+                           const float* b8, const float* cst, float* gate, hipStream_t s) {
+  if (hd % 8 || ldx % 8) return -1;
+  const long total = (long)B * T * heads;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(relpos_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, heads, hd, w8, b8, cst, gate);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// table[h][delta + T - 1] = rel_emb[bucket(delta)][h]   for delta = key - query in [-(T-1), T-1]
+__global__ __launch_bounds__(256) void relpos_table_kernel(const float* __restrict__ rel_emb, const int* __restrict__ bod, int max_t,
+                                                           int heads, int T, float* __restrict__ table) {
+  const int n = 2 * T - 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n * heads; i += gridDim.x * 256) {
+    const int h = i / n, j = i - h * n;
+    const int delta = j - (T - 1);
+    table[i] = rel_emb[bod[delta + max_t - 1] * heads + h];
+  }
+}
+
+int wfl_launch_relpos_table(const float* rel_emb, const int* bucket_of_delta, int max_t, int heads, int T, float* table, hipStream_t s) {
+  if (T > max_t) return -1;
+  const int n = (2 * T - 1) * heads;
+  hipLaunchKernelGGL(relpos_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rel_emb, bucket_of_delta, max_t, heads, T, table);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -109,7 +109,7 @@ def whisper_spec(a: WhisperArch) -> OrderedDict:
 def wavlm_spec(a: WavLMArch) -> OrderedDict:
     s = OrderedDict()
     d = a.d_model
-    s["encoder.masked_spec_embed"] = ((d,), "b", 1, 1.0)
+    # no `masked_spec_embed`: the reference zeroes mask_time_prob (model.py:76-78), so HF never creates it
     cin = 1
     for i, (c, k) in enumerate(zip(a.conv_dim, a.conv_kernel)):
         p = f"encoder.feature_extractor.conv_layers.{i}."
