@@ -205,3 +205,79 @@ def test_tag_decide_exact():
     sure = (mref - 0.5).abs() > 1e-5
     want = torch.where(mref < 0.5, torch.full_like(aref, 77), aref)
     assert torch.equal(ids.long()[sure], want[sure])
+
+
+# ---- the 256x256 tile kernel takes over when N % 256 == 0 and M >= 2048 (gemm256.hip)
+
+@pytest.mark.parametrize("K,N", [(64, 256), (512, 512), (1536, 256), (2048, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm256_linear_residual(K, N, act):
+    B, T = 3, 1500
+    a = G.Rows(B, T, K).set(_rand(B, T, K, seed=41))
+    x0 = _rand(B, T, N, seed=42)
+    x = G.Rows(B, T, N).set(x0)
+    w, bias = _rand(N, K, scale=K ** -0.5, seed=43), _rand(N, scale=0.1, seed=44)
+    wp, bp = G.pad_weight(w, bias)
+    assert B * a.P >= 2048
+    G.gemm(a.buf, a.lead * K, K, wp, B * a.P, N, a.P, T, x.buf, N, x.lead, x.P, bias=bp, res=x.buf, ldres=N, alpha=0.5, act=act)
+    torch.cuda.synchronize()
+    y = a.get() @ _bf(w).T + bias
+    y = [y, F.gelu(y), F.relu(y)][act]
+    _close(x.get(), _bf(x0) + 0.5 * y, what="gemm256")
+    assert x.halo_is_zero()
+
+
+def test_gemm256_conv_k31_glu_f32():
+    B, T, C = 2, 1500, 256
+    x0 = _rand(B, T, C, seed=45)
+    a = G.Rows(B, T, C).set(x0)
+    # dense k=31 conv as one contiguous-tap GEMM (the Conformer conv)
+    w, bias = _rand(C, C, 31, scale=(31 * C) ** -0.5, seed=46), _rand(C, scale=0.1, seed=47)
+    wp, bp = G.pad_weight(w.permute(0, 2, 1).reshape(C, 31 * C), bias)
+    out = G.Rows(B, T, C)
+    G.gemm(a.buf, (a.lead - 15) * C, C, wp, B * a.P, C, a.P, T, out.buf, C, out.lead, out.P, bias=bp, act=1)
+    torch.cuda.synchronize()
+    ref = F.gelu(F.conv1d(_bf(x0).transpose(1, 2), _bf(w), bias, padding=15)).transpose(1, 2)
+    _close(out.get(), ref, what="k31 conv 256")
+    # GLU (pointwise conv d -> 2d, rows interleaved 16 a | 16 gate)
+    d = C
+    w2, b2 = _rand(2 * d, d, scale=d ** -0.5, seed=48), _rand(2 * d, scale=0.2, seed=49)
+    rows, brow = torch.empty_like(w2), torch.empty_like(b2)
+    for g in range(d // 16):
+        rows[32 * g:32 * g + 16] = w2[16 * g:16 * g + 16]
+        rows[32 * g + 16:32 * g + 32] = w2[d + 16 * g:d + 16 * g + 16]
+        brow[32 * g:32 * g + 16] = b2[16 * g:16 * g + 16]
+        brow[32 * g + 16:32 * g + 32] = b2[d + 16 * g:d + 16 * g + 16]
+    wp2, bp2 = G.pad_weight(rows, brow)
+    o2 = G.Rows(B, T, d)
+    G.gemm(a.buf, a.lead * d, d, wp2, B * a.P, 2 * d, a.P, T, o2.buf, d, o2.lead, o2.P, bias=bp2, glu=1)
+    torch.cuda.synchronize()
+    _close(o2.get(), F.glu(a.get() @ _bf(w2).T + b2, dim=-1), what="glu 256")
+    # fp32 frame-row output (the BiLSTM input projection's shape)
+    w3, b3 = _rand(512, C, scale=C ** -0.5, seed=50), _rand(512, seed=51)
+    wp3, bp3 = G.pad_weight(w3, b3)
+    gx = torch.zeros(a.R, 512, device="cuda")
+    G.gemm(a.buf, a.lead * C, C, wp3, B * a.P, 512, a.P, T, gx, 512, a.lead, a.P, bias=bp3, out_f32=1)
+    torch.cuda.synchronize()
+    got = gx[a.lead:a.lead + B * a.P].view(B, a.P, 512)[:, :T]
+    _close(got, a.get() @ _bf(w3).T + b3, rtol=1e-3, atol=1e-3, what="f32 256")
+    # dilated taps + stride 2 through the big kernel
+    C2 = 64
+    x1 = _rand(B, 2 * T, C2, seed=52)
+    o3 = G.Rows(B, T, 256, halo=20, lead=16)
+    a3 = G.Rows(B, 2 * T, C2, lead=8, pitch=2 * o3.P, tail=512).set(x1)
+    w4, b4 = _rand(256, C2, 3, scale=(3 * C2) ** -0.5, seed=53), _rand(256, scale=0.1, seed=54)
+    wp4, bp4 = G.pad_weight(w4.permute(0, 2, 1).reshape(256, 3 * C2), b4)
+    G.gemm(a3.buf, (a3.lead - 1) * C2, 2 * C2, wp4, B * o3.P, 256, o3.P, T, o3.buf, 256, o3.lead, o3.P, bias=bp4, act=1)
+    torch.cuda.synchronize()
+    ref = F.gelu(F.conv1d(_bf(x1).transpose(1, 2), _bf(w4), b4, stride=2, padding=1)).transpose(1, 2)
+    _close(o3.get(), ref, what="stride-2 conv 256")
+    x2 = _rand(B, T, 128, seed=55)
+    a4 = G.Rows(B, T, 128).set(x2)
+    w5, b5 = _rand(256, 128, 3, scale=(3 * 128) ** -0.5, seed=56), _rand(256, scale=0.1, seed=57)
+    wp5, bp5 = G.pad_weight(w5.permute(0, 2, 1).reshape(256, 3 * 128), b5)
+    o5 = G.Rows(B, T, 256)
+    G.gemm(a4.buf, (a4.lead - 4) * 128, 128, wp5, B * a4.P, 256, a4.P, T, o5.buf, 256, o5.lead, o5.P, bias=bp5, act=2, cin=128, tap_stride=4 * 128)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv1d(_bf(x2).transpose(1, 2), _bf(w5), b5, padding=4, dilation=4)).transpose(1, 2)
+    _close(o5.get(), ref, what="dilated conv 256")

@@ -32,7 +32,7 @@ extern "C" int diag_gemm(const void* A, long lda, int cin, long tap_stride, cons
 }
 ''')
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-DWFL_GEMM_STAMPS", f"-DNSTAGE={nstage}", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-I", SRC,
-           "-shared", os.path.join(SRC, "gemm.hip"), drv, "-o", lib]
+           "-shared", os.path.join(SRC, "gemm.hip"), os.path.join(SRC, "gemm256.hip"), drv, "-o", lib]
     subprocess.run(cmd, check=True)
     return lib
 
@@ -53,7 +53,8 @@ def main(nstage):
         W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         Cb = torch.zeros(R, N, dtype=torch.bfloat16, device="cuda")
         bias = torch.randn(N, device="cuda")
-        tiles = ((M + 127) // 128) * (N // 128)
+        big = os.environ.get("WFL_GEMM_TILE", "256") != "128" and N % 256 == 0
+        tiles = ((M + 255) // 256) * (N // 256) if big else ((M + 127) // 128) * (N // 128)
         stamps = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         # conv-like addressing for K > kin: lda = 512 with contiguous taps (k31 conv)

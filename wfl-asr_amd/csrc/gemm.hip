@@ -13,6 +13,7 @@
 // consecutive output channels of one frame and stores 8 bytes; blocks in the V range of a packed q|k|v
 // projection swap the roles back and write V transposed ([channel][frame]) for the attention kernel's P.V.
 #include "common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -363,10 +364,25 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s);   // gemm256.hip; returns 1 when it does not take the shape
+
+static int tile_pref() {
+  static int pref = -1;
+  if (pref < 0) {
+    const char* e = getenv("WFL_GEMM_TILE");      // "128" forces the 128x128 kernel (A/B runs, tests)
+    pref = (e && atoi(e) == 128) ? 128 : 256;
+  }
+  return pref;
+}
+
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.N % BN || a.K <= 0 || a.K % BK || a.cin <= 0 || a.cin % BK || a.P <= 0 || a.P % 8 ||
       (!a.out_f32 && a.ldc % 8) || (a.res && a.ldres % 8) || (a.pos && a.ldpos % 8) || (a.Vt && a.vt_n0 % BN))
     return -1;
+  if (tile_pref() == 256) {
+    const int r = wfl_launch_gemm256(a, s);
+    if (r != 1) return r;
+  }
   if (a.glu) {
     if (a.out_f32 || a.act != WFL_ACT_NONE || a.Vt) return -1;
     return launch_t<WFL_ACT_NONE, true, false, false>(a, s);

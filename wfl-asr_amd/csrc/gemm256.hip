@@ -1,0 +1,312 @@
+// 256 x 256 x 32 variant of the bf16 MFMA GEMM (same contract and epilogues as gemm.hip, no V^T path).
+//
+// Why: tools/gemm_diag.py shows the 128x128 tile is bound by L2 -> LDS bandwidth per CU (~50-70 GB/s): each K step
+// moves 32 KiB for 2.1 MFLOP.  A 256x256 block tile moves the same 32 KiB per 32-deep K step for 4.2 MFLOP, i.e. twice
+// the arithmetic intensity (128 FLOP/B), and with M = B*pitch ~ 24k rows its tile counts (190 per 512 output columns)
+// fill the 256 CUs in whole rounds.
+//
+// 512 threads = 8 waves (2 per SIMD) in 2(M) x 4(N); each wave owns 128 frames x 64 channels = 8 x 4 MFMA 16x16x32
+// accumulators (128 VGPRs).  Operand tiles arrive by global_load_lds_dwordx4 into a 4-deep ring of 32 KiB stages
+// (counted vmcnt, raw s_barrier).  Rows are 64 bytes (32 bf16), so four rows share a 256-byte bank row; the 16-byte
+// chunk swizzle chunk' = chunk ^ ((-(row >> 2)) & 3) makes every ds_read_b128 lane group hit 16 distinct slots.
+// The K step is split in two halves that share the weight fragments:
+//     read X[4:8](kt) | 16 MFMA on X[0:4](kt)
+//     wait tile kt+1 ; s_barrier ; prefetch tile kt+3
+//     read W(kt+1), X[0:4](kt+1) | 16 MFMA on X[4:8](kt)
+// The epilogue leaves through LDS in two 128-row halves (fp32, pitch 260) exactly like gemm.hip's.
+#include "common.h"
+
+#define BM2 256
+#define BN2 256
+#define BK2 32
+#define ST2 (2 * 256 * BK2 * 2)          // one stage: frame tile + weight tile = 32 KiB
+#define NST2 4
+#define EP2 260                           // epilogue pitch (floats)
+#define LDS2 (128 * EP2 * 4)              // 133,120 B >= NST2 * ST2
+
+typedef __attribute__((address_space(1))) const void* gptr2_t;
+typedef __attribute__((address_space(3))) void* lptr2_t;
+
+static __device__ __forceinline__ void glds16b(const bf16_t* g, char* l) {
+  __builtin_amdgcn_global_load_lds((gptr2_t)g, (lptr2_t)l, 16, 0, 0);
+}
+static __device__ __forceinline__ int swz2(int row) { return (-(row >> 2)) & 3; }
+
+#ifdef WFL_GEMM_STAMPS
+#define STAMP2(k) do { if (tid == 0 && p.stamps) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP2(k) do { } while (0)
+#endif
+
+template <int ACT, bool GLU, bool OUTF32>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  STAMP2(0);
+  const int tiles_n = p.N / BN2;
+  const int tiles_m = (p.M + BM2 - 1) / BM2;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN2;
+  const int wm = (wid >> 2) * 128, wn = (wid & 3) * 64;
+
+  // staging: wave w issues loads i = 0,1 for each operand; load covers tile rows (2w+i)*16 .. +16,
+  // lane l -> row (l >> 2), physical chunk (l & 3), logical chunk = phys ^ swz2(row)
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wid * 2 + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ swz2(row);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    a_src[i] = p.A + (long)am * p.lda + chunk * 8;
+    w_src[i] = p.W + (long)(n0 + row) * p.K + chunk * 8;
+  }
+  const int nk = p.K / BK2;
+  auto stage = [&](int buf, int kt) {
+    const int k0 = kt * BK2;
+    const int tap = k0 / p.cin;
+    const long koff = (long)tap * p.tap_stride + (k0 - tap * p.cin);
+    char* base = smem + buf * ST2 + wid * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16b(a_src[i] + koff, base + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16b(w_src[i] + k0, base + 256 * BK2 * 2 + i * 1024);
+  };
+
+  const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz2(lane & 15)) << 4);
+  const int x_off = wm * 64 + frag_off;                       // frame tile, + u * 1024
+  const int w_off = 256 * BK2 * 2 + wn * 64 + frag_off;       // weight tile, + v * 1024
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 bj[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    bj[v] = p.bias ? *(const f32x4*)(p.bias + n0 + wn + v * 16 + (lane >> 4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define SB2() __builtin_amdgcn_sched_barrier(0)
+#define LGKM2() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define WAIT2(later)                                                          \
+  do {                                                                        \
+    if ((later) >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+    else if ((later) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+  } while (0)
+#define LDW(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = *(const bf16x8*)(smem + (slot) * ST2 + w_off + v_ * 1024)
+#define LDX(dst, slot, u0) _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) dst[u_] = *(const bf16x8*)(smem + (slot) * ST2 + x_off + ((u0) + u_) * 1024)
+#define MMA2(fw, fx, u0)                                                      \
+  _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                            \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_)                          \
+      acc[(u0) + u_][v_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v_], fx[u_], acc[(u0) + u_][v_], 0, 0, 0)
+
+  bf16x8 fw[4], fwn[4], fx0[4], fx1[4];
+#pragma unroll
+  for (int t = 0; t < NST2 - 1; ++t)
+    if (t < nk) stage(t, t);
+  {
+    const int later = (nk - 1 < NST2 - 2) ? nk - 1 : NST2 - 2;
+    WAIT2(later);
+    __builtin_amdgcn_s_barrier();
+    STAMP2(1);
+    LDW(fw, 0);
+    LDX(fx0, 0, 0);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int slot = kt % NST2;
+    LGKM2();
+    LDX(fx1, slot, 4);
+    SB2();
+    MMA2(fw, fx0, 0);
+    SB2();
+    {
+      const int last = (kt + NST2 - 2 < nk - 1) ? kt + NST2 - 2 : nk - 1;
+      WAIT2(last - (kt + 1));
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST2 - 1 < nk) stage((kt + NST2 - 1) % NST2, kt + NST2 - 1);
+    }
+    LGKM2();
+    LDW(fwn, (kt + 1) % NST2);
+    LDX(fx0, (kt + 1) % NST2, 0);
+    SB2();
+    MMA2(fw, fx1, 4);
+    SB2();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fw[v] = fwn[v];
+  }
+#undef SB2
+#undef LGKM2
+#undef WAIT2
+#undef LDW
+#undef LDX
+#undef MMA2
+
+  // ------------------------------------------------------------------ epilogue: two 128-row halves through LDS
+  constexpr int NC = GLU ? 128 : 256;
+  constexpr int EP = NC + 4;
+  constexpr int CP = NC / 8;                  // 8-channel chunks per row
+  constexpr int RPP = 512 / CP;               // rows per pass
+  constexpr int NP = 128 / RPP;
+  float* stg = (float*)smem;
+  STAMP2(2);
+#ifdef WFL_GEMM_STAMPS
+  if (tid == 0 && p.stamps) { p.stamps[(long)blockIdx.x * 8 + 6] = 0; p.stamps[(long)blockIdx.x * 8 + 7] = blockIdx.x; }
+#endif
+  const int cidx = tid % CP;
+  const int nb = (GLU ? n0 / 2 : n0) + cidx * 8;
+  const int nvalid = GLU ? p.n_valid / 2 : p.n_valid;
+
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                          // operand ring / previous half fully consumed
+    if ((wid >> 2) == half) {
+      // acc[u][v][e]: frame ml = 16u + c, channel nl = wn + 16v + 4g + e
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ml = u * 16 + (lane & 15);
+        const float* cb = nullptr;
+        if (p.clip_bias) {
+          int m = m0 + half * 128 + ml;
+          m = m < p.M ? m : p.M - 1;
+          cb = p.clip_bias + (long)p.clip_idx[m / p.P] * p.clip_ld;
+        }
+        if (GLU) {
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const f32x4 ba = bj[2 * jp], bg = bj[2 * jp + 1];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc[u][2 * jp][e] + ba[e]) * sigmoidf_(acc[u][2 * jp + 1][e] + bg[e]);
+            *(f32x4*)(stg + ml * EP + wn / 2 + jp * 16 + (lane >> 4) * 4) = v;
+          }
+        } else {
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4) {
+            const int nl = wn + v4 * 16 + (lane >> 4) * 4;
+            f32x4 v = acc[u][v4] + bj[v4];
+            if (cb) { const f32x4 bb = *(const f32x4*)(cb + n0 + nl); v += bb; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
+            *(f32x4*)(stg + ml * EP + nl) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (half == 0) STAMP2(3);
+    if (nb < nvalid) {
+      long orow[NP];
+      int tt[NP];
+      bool ok[NP];
+      {
+        const int m = m0 + half * 128 + tid / CP;
+        int b = m / p.P, t = m - b * p.P;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+          ok[pass] = (m + pass * RPP < p.M) && t < p.T;
+          tt[pass] = t;
+          orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
+          t += RPP;
+          if (t >= p.P) { t -= p.P; ++b; }
+        }
+      }
+      // residual rows are prefetched four passes at a time (all accumulators of the other half are still live, so
+      // registers are tight); the positional row (one launch per forward) is read in place
+      constexpr int GP = NP < 4 ? NP : 4;
+#pragma unroll
+      for (int g0 = 0; g0 < NP; g0 += GP) {
+        bf16x8 rr[GP];
+        if (p.res) {
+#pragma unroll
+          for (int q = 0; q < GP; ++q) rr[q] = *(const bf16x8*)(p.res + orow[g0 + q] * p.ldres + nb);
+        }
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+          const int pass = g0 + q;
+          if (!ok[pass]) continue;
+          const int r = pass * RPP + tid / CP;
+          float v[8];
+          {
+            const f32x4 v0 = *(const f32x4*)(stg + r * EP + cidx * 8);
+            const f32x4 v1 = *(const f32x4*)(stg + r * EP + cidx * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+          }
+          if (p.pos) {
+            const bf16x8 pp = *(const bf16x8*)(p.pos + (long)tt[pass] * p.ldpos + nb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[e]);
+          }
+          if (p.res) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[q][e]) + p.alpha * v[e];
+          }
+          if (OUTF32) {
+            float* o = (float*)p.C + orow[pass] * p.ldc + nb;
+            if (nb + 8 <= nvalid && (p.ldc & 3) == 0) {
+              *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+              *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (nb + e < nvalid) o[e] = v[e];
+            }
+          } else if (nb + 8 <= nvalid) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+            *(bf16x8*)((bf16_t*)p.C + orow[pass] * p.ldc + nb) = o;
+          } else {
+            bf16_t* o = (bf16_t*)p.C + orow[pass] * p.ldc + nb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (nb + e < nvalid) o[e] = f2bf(v[e]);
+          }
+        }
+      }
+    }
+  }
+  STAMP2(4);
+}
+
+template <int ACT, bool GLU, bool OUTF32>
+static int launch256_t(const GemmArgs& a, hipStream_t s) {
+  const int tiles = ((a.M + BM2 - 1) / BM2) * (a.N / BN2);
+  auto k = gemm256_kernel<ACT, GLU, OUTF32>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return -2;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(512), LDS2, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Returns 1 when this kernel does not take the shape (caller falls back to the 128x128 kernel).
+int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s) {
+  if (a.Vt || a.N % BN2 || a.K % BK2 || a.cin % BK2 || a.M < 2048) return 1;
+  if (a.glu) return launch256_t<WFL_ACT_NONE, true, false>(a, s);
+  if (a.out_f32) {
+    if (a.act == WFL_ACT_NONE) return launch256_t<WFL_ACT_NONE, false, true>(a, s);
+    return 1;
+  }
+  switch (a.act) {
+    case WFL_ACT_NONE: return launch256_t<WFL_ACT_NONE, false, false>(a, s);
+    case WFL_ACT_GELU: return launch256_t<WFL_ACT_GELU, false, false>(a, s);
+    case WFL_ACT_RELU: return launch256_t<WFL_ACT_RELU, false, false>(a, s);
+  }
+  return 1;
+}
