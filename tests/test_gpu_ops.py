@@ -281,3 +281,18 @@ def test_gemm256_conv_k31_glu_f32():
     torch.cuda.synchronize()
     ref = F.relu(F.conv1d(_bf(x2).transpose(1, 2), _bf(w5), b5, padding=4, dilation=4)).transpose(1, 2)
     _close(o5.get(), ref, what="dilated conv 256")
+
+
+def test_gemm256_both_block_heights():
+    """The launcher picks a 192- or 256-row block by a cost model; run the big-tile tests with each forced."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("WFL_GEMM_BM"):
+        pytest.skip("inner run")
+    for bm in ("192", "256"):
+        env = dict(os.environ, WFL_GEMM_BM=bm)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-k", "gemm256_linear or gemm256_conv",
+                            "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, (bm, r.stdout[-3000:])

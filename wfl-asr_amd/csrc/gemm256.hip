@@ -15,6 +15,7 @@
 //     read W(kt+1), X[0:4](kt+1) | 16 MFMA on X[4:8](kt)
 // The epilogue leaves through LDS in two 128-row halves (fp32, pitch 260) exactly like gemm.hip's.
 #include "common.h"
+#include <cstdlib>
 
 #define BM2 256
 #define BN2 256
@@ -38,8 +39,9 @@ static __device__ __forceinline__ int swz2(int row) { return (-(row >> 2)) & 3; 
 #define STAMP2(k) do { } while (0)
 #endif
 
-template <int ACT, bool GLU, bool OUTF32>
+template <int ACT, bool GLU, bool OUTF32, int MT>   // MT = 16-frame MFMA tiles per wave: 8 -> 256-row block, 6 -> 192-row block
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+  constexpr int BMV = MT * 32;              // rows of the block tile that are computed (the staged tile is always 256 rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
   STAMP2(0);
   const int tiles_n = p.N / BN2;
-  const int tiles_m = (p.M + BM2 - 1) / BM2;
+  const int tiles_m = (p.M + BMV - 1) / BMV;
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
   const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-  const int m0 = tile_m * BM2, n0 = tile_n * BN2;
-  const int wm = (wid >> 2) * 128, wn = (wid & 3) * 64;
+  const int m0 = tile_m * BMV, n0 = tile_n * BN2;
+  const int wm = (wid >> 2) * (MT * 16), wn = (wid & 3) * 64;
 
   // staging: wave w issues loads i = 0,1 for each operand; load covers tile rows (2w+i)*16 .. +16,
   // lane l -> row (l >> 2), physical chunk (l & 3), logical chunk = phys ^ swz2(row)
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   const int x_off = wm * 64 + frag_off;                       // frame tile, + u * 1024
   const int w_off = 256 * BK2 * 2 + wn * 64 + frag_off;       // weight tile, + v * 1024
 
-  f32x4 acc[8][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
+  for (int u = 0; u < MT; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -107,9 +109,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
   } while (0)
 #define LDW(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = *(const bf16x8*)(smem + (slot) * ST2 + w_off + v_ * 1024)
-#define LDX(dst, slot, u0) _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) dst[u_] = *(const bf16x8*)(smem + (slot) * ST2 + x_off + ((u0) + u_) * 1024)
-#define MMA2(fw, fx, u0)                                                      \
-  _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                            \
+#define LDX(dst, slot, u0, cnt) _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) dst[u_] = *(const bf16x8*)(smem + (slot) * ST2 + x_off + ((u0) + u_) * 1024)
+#define MMA2(fw, fx, u0, cnt)                                                 \
+  _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_)                        \
     _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_)                          \
       acc[(u0) + u_][v_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v_], fx[u_], acc[(u0) + u_][v_], 0, 0, 0)
 
@@ -123,14 +125,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     STAMP2(1);
     LDW(fw, 0);
-    LDX(fx0, 0, 0);
+    LDX(fx0, 0, 0, 4);
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt % NST2;
     LGKM2();
-    LDX(fx1, slot, 4);
+    LDX(fx1, slot, 4, MT - 4);
     SB2();
-    MMA2(fw, fx0, 0);
+    MMA2(fw, fx0, 0, 4);
     SB2();
     {
       const int last = (kt + NST2 - 2 < nk - 1) ? kt + NST2 - 2 : nk - 1;
@@ -140,9 +142,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
     LGKM2();
     LDW(fwn, (kt + 1) % NST2);
-    LDX(fx0, (kt + 1) % NST2, 0);
+    LDX(fx0, (kt + 1) % NST2, 0, 4);
     SB2();
-    MMA2(fw, fx1, 4);
+    MMA2(fw, fx1, 4, MT - 4);
     SB2();
 #pragma unroll
     for (int v = 0; v < 4; ++v) fw[v] = fwn[v];
@@ -154,12 +156,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #undef LDX
 #undef MMA2
 
-  // ------------------------------------------------------------------ epilogue: two 128-row halves through LDS
+  // ------------------------------------------------------------------ epilogue: two half-blocks through LDS
   constexpr int NC = GLU ? 128 : 256;
   constexpr int EP = NC + 4;
   constexpr int CP = NC / 8;                  // 8-channel chunks per row
   constexpr int RPP = 512 / CP;               // rows per pass
-  constexpr int NP = 128 / RPP;
+  constexpr int HR = MT * 16;                 // rows per half
+  constexpr int NP = (HR + RPP - 1) / RPP;
   float* stg = (float*)smem;
   STAMP2(2);
 #ifdef WFL_GEMM_STAMPS
@@ -169,20 +172,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   const int nb = (GLU ? n0 / 2 : n0) + cidx * 8;
   const int nvalid = GLU ? p.n_valid / 2 : p.n_valid;
 
+  // bias / per-clip bias / activation on ALL eight waves at once (the staging below runs one half at a time)
+  if (!GLU) {
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const float* cb = nullptr;
+      if (p.clip_bias) {
+        int m = m0 + wm + u * 16 + (lane & 15);
+        m = m < p.M ? m : p.M - 1;
+        cb = p.clip_bias + (long)p.clip_idx[m / p.P] * p.clip_ld;
+      }
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        f32x4 v = acc[u][v4] + bj[v4];
+        if (cb) { const f32x4 bb = *(const f32x4*)(cb + n0 + wn + v4 * 16 + (lane >> 4) * 4); v += bb; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
+        acc[u][v4] = v;
+      }
+    }
+  }
+
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     __syncthreads();                          // operand ring / previous half fully consumed
     if ((wid >> 2) == half) {
       // acc[u][v][e]: frame ml = 16u + c, channel nl = wn + 16v + 4g + e
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < MT; ++u) {
         const int ml = u * 16 + (lane & 15);
-        const float* cb = nullptr;
-        if (p.clip_bias) {
-          int m = m0 + half * 128 + ml;
-          m = m < p.M ? m : p.M - 1;
-          cb = p.clip_bias + (long)p.clip_idx[m / p.P] * p.clip_ld;
-        }
         if (GLU) {
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
@@ -194,14 +212,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
           }
         } else {
 #pragma unroll
-          for (int v4 = 0; v4 < 4; ++v4) {
-            const int nl = wn + v4 * 16 + (lane >> 4) * 4;
-            f32x4 v = acc[u][v4] + bj[v4];
-            if (cb) { const f32x4 bb = *(const f32x4*)(cb + n0 + nl); v += bb; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e]);
-            *(f32x4*)(stg + ml * EP + nl) = v;
-          }
+          for (int v4 = 0; v4 < 4; ++v4) *(f32x4*)(stg + ml * EP + wn + v4 * 16 + (lane >> 4) * 4) = acc[u][v4];
         }
       }
     }
@@ -212,11 +223,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
       int tt[NP];
       bool ok[NP];
       {
-        const int m = m0 + half * 128 + tid / CP;
+        const int m = m0 + half * HR + tid / CP;
         int b = m / p.P, t = m - b * p.P;
 #pragma unroll
         for (int pass = 0; pass < NP; ++pass) {
-          ok[pass] = (m + pass * RPP < p.M) && t < p.T;
+          ok[pass] = (m + pass * RPP < p.M) && t < p.T && (tid / CP + pass * RPP < HR);
           tt[pass] = t;
           orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
           t += RPP;
@@ -231,11 +242,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         bf16x8 rr[GP];
         if (p.res) {
 #pragma unroll
-          for (int q = 0; q < GP; ++q) rr[q] = *(const bf16x8*)(p.res + orow[g0 + q] * p.ldres + nb);
+          for (int q = 0; q < GP; ++q)
+            if (g0 + q < NP) rr[q] = *(const bf16x8*)(p.res + orow[g0 + q] * p.ldres + nb);
         }
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
           const int pass = g0 + q;
+          if (pass >= NP) continue;               // NP = 6 for the 192-row block
           if (!ok[pass]) continue;
           const int r = pass * RPP + tid / CP;
           float v[8];
@@ -282,10 +295,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   STAMP2(4);
 }
 
-template <int ACT, bool GLU, bool OUTF32>
-static int launch256_t(const GemmArgs& a, hipStream_t s) {
-  const int tiles = ((a.M + BM2 - 1) / BM2) * (a.N / BN2);
-  auto k = gemm256_kernel<ACT, GLU, OUTF32>;
+template <int ACT, bool GLU, bool OUTF32, int MT>
+static int launch256_mt(const GemmArgs& a, hipStream_t s) {
+  constexpr int BMV = MT * 32;
+  const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / BN2);
+  auto k = gemm256_kernel<ACT, GLU, OUTF32, MT>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return -2;
@@ -293,6 +307,20 @@ static int launch256_t(const GemmArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(k, dim3(tiles), dim3(512), LDS2, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Block height: 256 or 192 rows, whichever fills the 256 CUs in fewer / fuller rounds (one block per CU).  Cost model:
+// rounds * (rows + fixed per-block overhead worth ~96 rows).
+template <int ACT, bool GLU, bool OUTF32>
+static int launch256_t(const GemmArgs& a, hipStream_t s) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0; }
+  auto cost = [&](int bm) {
+    const long tiles = (long)((a.M + bm - 1) / bm) * (a.N / BN2);
+    return ((tiles + 255) / 256) * (long)(bm + 96);
+  };
+  const bool use192 = forced == 192 || (forced != 256 && cost(192) < cost(256));
+  return use192 ? launch256_mt<ACT, GLU, OUTF32, 6>(a, s) : launch256_mt<ACT, GLU, OUTF32, 8>(a, s);
 }
 
 // Returns 1 when this kernel does not take the shape (caller falls back to the 128x128 kernel).
