@@ -279,6 +279,33 @@ def test_wavlm_matches_reference_golden(name, golden_dir):
     assert torch.equal(again.logits, out.logits)
 
 
+@pytest.mark.parametrize("idx,B,L", [(3, 1, 160000), (2, 2, 48000)])
+def test_baseline_configs_3_and_4_vs_oracle(idx, B, L):
+    """BASELINE configs[3] (Whisper-small + full default head: BiLSTM H=384, Conformer head_dim 384) and configs[2]
+    (WavLM-large, layer-norm feature encoder + stable layer norm, BiLSTM H=512 + dilated stack) at their real widths,
+    on short clips so the CPU oracle finishes in seconds."""
+    cfg = synth.baseline_config(idx)
+    m, labels, sd_np = _build(cfg, 70, seed=40 + idx)
+    wav = synth.make_batch(900 + idx, B, L, seed=40 + idx)
+    lang = (np.arange(B) % 2).astype(np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True, want_hidden=True)
+    m.check(B, L)
+    lg, of, hid = _oracle(cfg, labels, sd_np, wav, lang)
+    h_err = (out.hidden.cpu() - hid).abs()
+    _note(f"cfg{idx + 1}_hidden", max=h_err.max(), mean=h_err.mean())
+    assert h_err.max() <= 0.25 and h_err.mean() <= 0.03
+    ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
+    err = (out.logits.cpu() - lg).abs()
+    safe = margin > 2 * float(err.max())
+    bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
+    _note(f"cfg{idx + 1}", logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
+          safe_frac=safe.float().mean(), argmax_bad=bad, argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()),
+          frames=int(arg_ref.numel()))
+    assert err.max() <= 1.0 and err.mean() <= 0.12          # deeper stacks (12-24 encoder layers): looser than cfg2
+    assert (out.offsets.cpu() - of).abs().max() <= 0.05
+    assert bad == 0 and safe.float().mean() >= 0.5
+
+
 def test_graph_replay_is_bit_identical():
     cfg = _tiny()
     m, labels, _ = _build(cfg, 5, seed=24)

@@ -125,7 +125,8 @@ def test_gemm_glu():
     _close(out.get(), ref, what="glu")
 
 
-@pytest.mark.parametrize("d,heads,T", [(64, 2, 100), (128, 2, 257), (512, 8, 1500), (512, 2, 300)])
+@pytest.mark.parametrize("d,heads,T", [(64, 2, 100), (128, 2, 257), (512, 8, 1500), (512, 2, 300), (768, 2, 300), (1024, 2, 200),
+                                       (1280, 2, 150)])
 def test_qkv_projection_and_attention(d, heads, T):
     """packed q|k|v GEMM (V written transposed) + flash attention vs softmax(q k^T / sqrt(hd)) v."""
     B = 2

@@ -254,6 +254,8 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+int wfl_launch_attention_big(const AttnArgs& a, hipStream_t s);   // attention_big.hip: head_dim 384 / 512 / 640
+
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldo % 4 || a.T <= 0) return -1;
   const int hd = a.d / a.heads;
@@ -270,6 +272,7 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
     case 64: return launch_attn<64, 2, true, false>(a, s);
     case 128: return launch_attn<128, 2, true, false>(a, s);
     case 256: return launch_attn<256, 1, false, false>(a, s);
+    case 384: case 512: case 640: return wfl_launch_attention_big(a, s);
   }
   return -4;   // unsupported head_dim
 }
