@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips per CPU-baseline call")
     ap.add_argument("--cpu-calls", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the HIP-event pass that times every GEMM launch")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one captured HIP graph per step")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one captured HIP graph per step instead of launching eagerly (experimental: measured gain "
+                         "< 1 %, and a replay was seen to diverge from eager when several graphs share the workspace)")
     ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (Whisper configs only)")
     ap.add_argument("--full-head", action="store_true",
                     help="Whisper-base + the reference's default config.yaml head (2-layer BiLSTM, 2 Conformer, 2 dilated convs)")
@@ -146,11 +148,9 @@ def main():
     lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
     T = model.num_frames(L)
     n_host = B * (world if rank == 0 else 1)
-    host_ids = torch.empty(n_host, T, dtype=torch.int32).pin_memory()
-    host_maxp = torch.empty(n_host, T, dtype=torch.float32).pin_memory()
-    host_offs = torch.empty(n_host, T, 2, dtype=torch.float32).pin_memory()
+    host_tags = torch.empty(n_host * T * 4, dtype=torch.int32).pin_memory()    # ids | max-prob | offsets, one copy
 
-    use_graph = not args.no_graph
+    use_graph = args.graph
 
     def step(graph=use_graph):
         out = model.label(wav, lang, threshold=0.5, graph=graph)
@@ -158,11 +158,12 @@ def main():
             ids, maxp, offs = gather_tags(out.ids, out.maxprob, out.offsets, dst=0)
             if rank != 0:
                 return
+            n = ids.numel()
+            host_tags[0:n].copy_(ids.reshape(-1), non_blocking=True)
+            host_tags[n:2 * n].copy_(maxp.reshape(-1).view(torch.int32), non_blocking=True)
+            host_tags[2 * n:4 * n].copy_(offs.reshape(-1).view(torch.int32), non_blocking=True)
         else:
-            ids, maxp, offs = out.ids, out.maxprob, out.offsets
-        host_ids.copy_(ids, non_blocking=True)
-        host_maxp.copy_(maxp, non_blocking=True)
-        host_offs.copy_(offs, non_blocking=True)
+            host_tags.copy_(out.packed, non_blocking=True)
 
     def fence():
         if world > 1:

@@ -5,7 +5,7 @@ Tolerances (bf16 weights/activations with fp32 accumulation vs the fp32 referenc
   log-mel (fp32 path)        |err| <= 2e-3 everywhere, mean |err| <= 1e-4         (near-floor bins are fp32-FFT noise)
   encoder hidden (LN output) |err| <= 0.08 abs (values are O(1)), mean |err| <= 0.012
   logits (std ~6.5)          |err| <= 0.6 abs, mean |err| <= 0.08
-  max-prob                   |err| <= 0.08;  offsets |err| <= 0.03
+  max-prob                   |err| <= 0.10;  offsets |err| <= 0.03
   tag ids                    identical on every frame whose fp32 top-2 logit margin > TAU = 0.5
                              and whose max-prob is further than 0.08 from the threshold; >= 60 % of frames qualify (the rest are near-ties or sit at the threshold)
 """
@@ -67,7 +67,7 @@ def _check_decisions(name, out, ref_logits, ref_offsets, o_id, thr):
           safe_frac=safe.float().mean(), argmax_bad=arg_bad, ids_bad=ids_bad,
           argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()), frames=int(arg_ref.numel()))
     assert err.max() <= 0.6 and err.mean() <= 0.08, (err.max(), err.mean())
-    assert mp_err.max() <= 0.08 and of_err.max() <= 0.03, (mp_err.max(), of_err.max())
+    assert mp_err.max() <= 0.10 and of_err.max() <= 0.03, (mp_err.max(), of_err.max())
     assert arg_bad == 0 and ids_bad == 0
     assert safe.float().mean() >= 0.60
 
@@ -117,7 +117,7 @@ def test_forward_matches_reference_golden(name, golden_dir):
           argmax_bad=arg_bad, ids_bad=ids_bad, argmax_all_mismatch=int((out.argmax.cpu().numpy() != g["argmax"]).sum()))
     assert hid_err.max() <= 0.08 and hid_err.mean() <= 0.012
     assert lg_err.max() <= 0.6 and lg_err.mean() <= 0.08
-    assert mp_err.max() <= 0.08 and of_err.max() <= 0.03
+    assert mp_err.max() <= 0.10 and of_err.max() <= 0.03
     assert arg_bad == 0 and ids_bad == 0 and safe.mean() >= 0.60
 
 
@@ -248,7 +248,7 @@ def test_bilstm_base_matches_reference_golden(golden_dir):
     _note("golden_base_full", logits_max=lg_err.max(), logits_mean=lg_err.mean(), maxprob_max=mp_err.max(),
           offsets_max=of_err.max(), safe_frac=safe.mean(), argmax_bad=arg_bad, ids_bad=ids_bad)
     assert lg_err.max() <= 0.6 and lg_err.mean() <= 0.08
-    assert mp_err.max() <= 0.08 and of_err.max() <= 0.03
+    assert mp_err.max() <= 0.10 and of_err.max() <= 0.03
     assert arg_bad == 0 and ids_bad == 0 and safe.mean() >= 0.60
     # batch of 20 clips = 2 clip groups (one partial): clip 0 is bit-identical to the B=1 run
     wav20 = np.concatenate([wav, synth.make_batch(7000, 19, L, seed=3)])

@@ -27,7 +27,7 @@ struct LogmelArgs {
   const int* lens;                  // [B] valid samples per clip, or null (=L)
   int L;                            // samples present per row
   int B, n_samples, n_frames, n_mels;
-  const float* Wc; const float* Ws; // [400][224]
+  const float* Wc; const float* Ws; // [200][224] folded tables: row j-1 <-> n = j (1..200)
   const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
   float* raw;                       // [B][n_frames][n_mels] log10 mel
   unsigned* clipmax;                // [B] ordered-uint max of raw (zeroed by the caller)
@@ -62,29 +62,45 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   __syncthreads();
 
   // ---- DFT on the fp32 MFMA.  Lane l: A[row = l&31][k = l>>5], B[k = l>>5][col = l&31].
+  // The periodic Hann window and the twiddles are symmetric about n = 200 (w[400-n] = w[n], cos(2 pi (400-n) k/400) =
+  // cos(2 pi n k/400), sin(...) = -sin(...)) and w[0] = 0, so
+  //     Re[k] = sum_{j=1..200} (x[j] + x[400-j]) * Wc[j][k],   Im[k] = sum_{j=1..200} (x[j] - x[400-j]) * Ws[j][k]
+  // with Wc[200] carrying a factor 1/2 (x[200] is counted twice by the fold) and Ws[200] = 0: 100 K-steps of 2
+  // instead of 200.  The twiddle rows come from L2 through a register ring PD steps deep (one wave per SIMD has
+  // nobody else to hide a ~1 us L2 round trip).
   const int r = lane & 31, kh = lane >> 5;
+  constexpr int PD = 10;                       // prefetch depth in K-steps; 100 steps = 10 rounds of PD
   for (int ct = wid; ct < NBIN_PAD / 32; ct += 4) {
     f32x16 re[2], im[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { re[rt][e] = 0.f; im[rt][e] = 0.f; }
-    const float* a0 = seg + 161 * r + kh;                 // frame r of row tile 0
-    const float* a1 = seg + 161 * (r + 32) + kh;
-    const float* bc = p.Wc + (long)kh * NBIN_PAD + ct * 32 + r;
+    const float* fa = seg + 161 * r;                         // frame r of row tile 0 (skewed: + n + n/160)
+    const float* fb = seg + 161 * (r + 32);
+    const float* bc = p.Wc + (long)kh * NBIN_PAD + ct * 32 + r;   // row j-1 of the folded tables, j = 1 + 2*step + kh
     const float* bs = p.Ws + (long)kh * NBIN_PAD + ct * 32 + r;
-    // the skew term (n / 160) is constant on [0,160), [160,320), [320,400): three loops, no per-step compare
+    float wcv[PD], wsv[PD];
 #pragma unroll
-    for (int part = 0; part < 3; ++part) {
-      const int nb = part * 160, ne = part == 2 ? NFFT : nb + 160;
-#pragma unroll 8
-      for (int n = nb; n < ne; n += 2) {
-        const float x0 = a0[n + part], x1 = a1[n + part];
-        const float c = bc[(long)n * NBIN_PAD], s = bs[(long)n * NBIN_PAD];
-        re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, c, re[0], 0, 0, 0);
-        im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, s, im[0], 0, 0, 0);
-        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, c, re[1], 0, 0, 0);
-        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, s, im[1], 0, 0, 0);
+    for (int q = 0; q < PD; ++q) { wcv[q] = bc[(long)(2 * q) * NBIN_PAD]; wsv[q] = bs[(long)(2 * q) * NBIN_PAD]; }
+    for (int sb = 0; sb < 100; sb += PD) {
+#pragma unroll
+      for (int q = 0; q < PD; ++q) {
+        const int step = sb + q;
+        const int j = 1 + 2 * step + kh;                     // 1..200
+        const int n2 = NFFT - j;                             // 200..399
+        const int a1 = j + (j >= 160 ? 1 : 0);
+        const int a2 = n2 + (n2 >= 320 ? 2 : 1);
+        const float x0a = fa[a1], x0b = fa[a2], x1a = fb[a1], x1b = fb[a2];
+        const float c = wcv[q], sn = wsv[q];
+        if (step + PD < 100) {
+          wcv[q] = bc[(long)(2 * (step + PD)) * NBIN_PAD];
+          wsv[q] = bs[(long)(2 * (step + PD)) * NBIN_PAD];
+        }
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0a + x0b, c, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0a - x0b, sn, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1a + x1b, c, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1a - x1b, sn, im[1], 0, 0, 0);
       }
     }
     // D[row][col]: col = lane&31 (bin), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (frame in the row tile)

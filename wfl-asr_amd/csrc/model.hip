@@ -76,6 +76,16 @@ int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
 int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s);
+struct ZeroMulti {
+  int n;
+  char* buf[10];
+  long ld_bytes[10];
+  long lead[10];
+  int P[10], T[10];
+  long tail_rows[10];
+  int B;
+};
+int wfl_launch_zero_halo_multi(const ZeroMulti& z, hipStream_t s);
 int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -362,14 +372,16 @@ static int finalize_whisper(wfl_model* m, Packer& P) {
   const int d = a.d_model, hd = d / a.enc_heads;
   // front-end tables: Hann-folded DFT matrix (periodic Hann as torch.hann_window(400))
   {
-    std::vector<float> wc((size_t)400 * 224, 0.f), ws((size_t)400 * 224, 0.f);
-    for (int n = 0; n < 400; ++n) {
-      const double hann = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / 400.0);
+    // folded about n = 200 (see logmel.hip): row j-1 <-> sample j = 1..200; Wc[200] carries the factor 1/2
+    std::vector<float> wc((size_t)200 * 224, 0.f), ws((size_t)200 * 224, 0.f);
+    for (int j = 1; j <= 200; ++j) {
+      const double hann = 0.5 - 0.5 * std::cos(2.0 * M_PI * j / 400.0);
+      const double fold = j == 200 ? 0.5 : 1.0;
       for (int k = 0; k <= 200; ++k) {
-        const int nk = (int)(((long)n * k) % 400);
+        const int nk = (int)(((long)j * k) % 400);
         const double ang = 2.0 * M_PI * nk / 400.0;
-        wc[(size_t)n * 224 + k] = (float)(hann * std::cos(ang));
-        ws[(size_t)n * 224 + k] = (float)(-hann * std::sin(ang));
+        wc[(size_t)(j - 1) * 224 + k] = (float)(fold * hann * std::cos(ang));
+        ws[(size_t)(j - 1) * 224 + k] = (float)(-hann * std::sin(ang));
       }
     }
     m->Wc = P.upload(wc);
@@ -838,6 +850,20 @@ struct Runner {
     if (r) rc = fail(r, "attention launch failed (" + std::to_string(r) + "; head_dim " + std::to_string(p.d / heads) + ")");
   }
 
+  ZeroMulti zm{};
+  void zero_add(long off, long ld_elems, long lead, int P, int T, long tail) {     // queued; zero_flush() launches once
+    const int k = zm.n++;
+    zm.buf[k] = ws + off; zm.ld_bytes[k] = ld_elems * 2; zm.lead[k] = lead; zm.P[k] = P; zm.T[k] = T;
+    zm.tail_rows[k] = (long)(P - T) + tail;
+  }
+  void zero_flush() {
+    if (rc || zm.n == 0) return;
+    zm.B = p.B;
+    const int r = wfl_launch_zero_halo_multi(zm, s);
+    zm.n = 0;
+    if (r) rc = fail(r, "zero_halo launch failed");
+  }
+
   void zero(long off, long ld_elems, long lead, int P, int T, long tail) {
     if (rc) return;
     // `tail` = rows behind the last clip's pitch; the kernel counts from the last clip's last valid frame
@@ -888,18 +914,20 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
 
   if (p.T <= 0) return fail(-1, "wfl_forward: clip too short for the encoder");
   // halos of every frame-row buffer (cheap; keeps the layout invariant independent of the workspace's history)
-  R.zero(p.X, d, p.lead, p.P, p.T, p.tail);
-  R.zero(p.Y, d, p.lead, p.P, p.T, p.tail);
-  R.zero(p.ATT, d, p.lead, p.P, p.T, p.tail);
-  R.zero(p.QK, 2 * d, p.lead, p.P, p.T, p.tail);
-  R.zero(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
+  R.zero_add(p.X, d, p.lead, p.P, p.T, p.tail);
+  R.zero_add(p.Y, d, p.lead, p.P, p.T, p.tail);
+  R.zero_add(p.ATT, d, p.lead, p.P, p.T, p.tail);
+  R.zero_add(p.QK, 2 * d, p.lead, p.P, p.T, p.tail);
+  R.zero_add(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
+  if (a.encoder_type == WFL_ENC_WHISPER) {
+    R.zero_add(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
+    R.zero_add(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
+  }
+  R.zero_flush();
   if (R.rc) return R.rc;
 
   if (a.encoder_type == WFL_ENC_WHISPER) {
     // ---- Whisper encoder (HF modeling_whisper.py:618-642)
-    R.zero(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
-    R.zero(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
-    if (R.rc) return R.rc;
     const int r = run_logmel(m, p, R.ws, wav, ldw, lens, nullptr, R.s);
     if (r) return fail(r, "logmel launch failed");
     bf16_t* mel = R.buf(p.mel);

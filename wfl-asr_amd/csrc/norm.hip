@@ -154,3 +154,46 @@ int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s) {
   hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, value);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// One launch for all frame-row buffers of a forward (same clip geometry per entry, different widths / pitches).
+struct ZeroMulti {
+  int n;
+  char* buf[10];
+  long ld_bytes[10];
+  long lead[10];
+  int P[10], T[10];
+  long tail_rows[10];
+  int B;
+};
+
+__global__ __launch_bounds__(256) void zero_halo_multi_kernel(ZeroMulti z) {
+  const int k = blockIdx.y;
+  if (k >= z.n) return;
+  char* buf = z.buf[k];
+  const long ld_bytes = z.ld_bytes[k], lead = z.lead[k], tail_rows = z.tail_rows[k];
+  const int P = z.P[k], T = z.T[k], B = z.B;
+  const int halo = P - T;
+  const long nrows = lead + (long)B * halo + tail_rows - halo;
+  const long chunks_per_row = ld_bytes >> 4;
+  const long total = nrows * chunks_per_row;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long hr = i / chunks_per_row, ch = i - hr * chunks_per_row;
+    long row;
+    if (hr < lead) row = hr;
+    else {
+      const long kk = hr - lead;
+      const long b = kk / halo;
+      if (b < B - 1) row = lead + b * P + T + (kk - b * halo);
+      else row = lead + (long)(B - 1) * P + T + (kk - (long)(B - 1) * halo);
+    }
+    *(uint4*)(buf + row * ld_bytes + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+}
+
+int wfl_launch_zero_halo_multi(const ZeroMulti& z, hipStream_t s) {
+  if (z.n <= 0 || z.n > 10) return -1;
+  for (int k = 0; k < z.n; ++k)
+    if (z.ld_bytes[k] % 16 || z.P[k] <= z.T[k] || z.tail_rows[k] < z.P[k] - z.T[k]) return -1;
+  hipLaunchKernelGGL(zero_halo_multi_kernel, dim3(256, z.n), dim3(256), 0, s, z);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -38,7 +38,7 @@ def load_config(config_path="config.yaml"):
 class Labeler:
     """Model + sidecar files loaded once; `label_files` runs the batched hot loop."""
 
-    def __init__(self, config_path, checkpoint_path, device="cuda", batch_size=16, use_graph=True):
+    def __init__(self, config_path, checkpoint_path, device="cuda", batch_size=16, use_graph=False):
         self.config = load_config(config_path) if isinstance(config_path, (str, os.PathLike)) else config_path
         dev = torch.device(device)
         if dev.type != "cuda":

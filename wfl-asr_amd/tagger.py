@@ -29,6 +29,7 @@ class TagBatch:
     def __init__(self, ids, argmax, maxprob, offsets, logits=None, hidden=None):
         self.ids, self.argmax, self.maxprob, self.offsets = ids, argmax, maxprob, offsets
         self.logits, self.hidden = logits, hidden
+        self.packed = None      # int32 view over ids | maxprob | offsets (one contiguous D2H copy)
 
 
 class BIOPhonemeTagger:
@@ -142,12 +143,18 @@ class BIOPhonemeTagger:
         _lib.check(rc, "wfl_forward")
 
     def _alloc_out(self, B, T, dev, want_logits, want_hidden) -> "TagBatch":
+        """ids | maxprob | offsets | argmax live in ONE allocation so the host side needs a single D2H copy
+        (`TagBatch.packed` = the first 4*B*T words: ids, max-prob bits, offsets bits)."""
         Cn = len(self.label_list)
-        return TagBatch(
-            torch.empty(B, T, dtype=torch.int32, device=dev), torch.empty(B, T, dtype=torch.int32, device=dev),
-            torch.empty(B, T, dtype=torch.float32, device=dev), torch.empty(B, T, 2, dtype=torch.float32, device=dev),
+        n = B * T
+        blob = torch.empty(5 * n, dtype=torch.int32, device=dev)
+        out = TagBatch(
+            blob[0:n].view(B, T), blob[4 * n:5 * n].view(B, T), blob[n:2 * n].view(torch.float32).view(B, T),
+            blob[2 * n:4 * n].view(torch.float32).view(B, T, 2),
             torch.empty(B, T, Cn, dtype=torch.float32, device=dev) if want_logits else None,
             torch.empty(B, T, self.hidden_size, dtype=torch.float32, device=dev) if want_hidden else None)
+        out.packed = blob[0:4 * n]
+        return out
 
     @torch.no_grad()
     def label(self, input_values: torch.Tensor, lang_id=None, threshold: float = 0.0, lens=None,
@@ -155,9 +162,10 @@ class BIOPhonemeTagger:
               graph: bool = False) -> TagBatch:
         """The batched fast path: [B, L] fp32 16 kHz clips -> per-frame decisions (all on the GPU).
 
-        graph=True replays the whole forward (about 100 kernel launches) as one captured HIP graph per
-        (B, L, mode) signature; inputs are copied into static buffers and the returned tensors are the graph's
-        static outputs (consume them before the next call with the same signature)."""
+        graph=True (experimental, off by default everywhere) replays the whole forward (about 100 kernel launches)
+        as one captured HIP graph per (B, L, mode) signature; inputs are copied into static buffers and the returned
+        tensors are the graph's static outputs (consume them before the next call with the same signature).  The
+        kernels are long enough that eager launches already keep the GPU busy (graph gain measured < 1 %)."""
         if not self._ready:
             raise _lib.WflError("load_state_dict() has not been called")
         if not input_values.is_cuda:
@@ -211,10 +219,12 @@ class BIOPhonemeTagger:
             st["graph"] = cg
             self._graphs[key] = g = st
         g["x"].copy_(x, non_blocking=True)
+        # small host-side vectors: blocking copies (an async copy from pageable memory may read the source after
+        # the caller has dropped it)
         if lang_t is not None:
-            g["lang"].copy_(lang_t, non_blocking=True)
+            g["lang"].copy_(lang_t, non_blocking=lang_t.is_cuda)
         if lens_t is not None:
-            g["lens"].copy_(lens_t, non_blocking=True)
+            g["lens"].copy_(lens_t, non_blocking=lens_t.is_cuda)
         g["graph"].replay()
         return g["out"]
 
