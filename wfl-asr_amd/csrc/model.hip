@@ -788,19 +788,6 @@ struct Runner {
             const bf16_t* pos = nullptr, long ldpos = 0, const float* clip_bias = nullptr, const int* clip_idx = nullptr,
             int clip_ld = 0) {
     if (rc) return;
-    if (Vt && vt_n0 > 0 && vt_n0 % 256 == 0 && W.N > vt_n0) {
-      // packed q|k|v projection: q|k columns through the 256x256 kernel, the V columns through the 128x128 kernel's
-      // transposed-store path (two launches, no role-swap code in the big kernel)
-      Lin qk = W, vv = W;
-      qk.N = vt_n0; qk.n_valid = vt_n0;
-      vv.W = W.W + (long)vt_n0 * W.K; vv.bias = W.bias ? W.bias + vt_n0 : nullptr;
-      vv.N = W.N - vt_n0; vv.n_valid = W.n_valid - vt_n0;
-      gemm(A, lda, qk, M, P, T, C, ldc, c_lead, c_pitch, act, res, ldres, alpha, cin, tap_stride, glu, out_f32, nullptr, 0, pos, ldpos,
-           clip_bias, clip_idx, clip_ld);
-      gemm(A, lda, vv, M, P, T, C, ldc, c_lead, c_pitch, act, res, ldres, alpha, cin, tap_stride, glu, out_f32, Vt, 0, pos, ldpos,
-           clip_bias, clip_idx, clip_ld);
-      return;
-    }
     GemmArgs g{};
     g.A = A; g.lda = lda;
     g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
