@@ -127,10 +127,11 @@ int32_t wfl_logmel(wfl_model* m, const float* wav, int64_t ldw, const int32_t* l
 int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride, const void* W, int32_t M, int32_t N,
                     int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead,
                     int32_t c_pitch, const float* bias, const void* res, int64_t ldres, float alpha, int32_t act,
-                    int32_t glu, int32_t out_f32, void* Vt, int32_t vt_n0, void* stream);
+                    int32_t glu, int32_t out_f32, void* stream);
 
-/* softmax(q k^T) v per (clip, head); QK rows hold [q | k] (q pre-scaled by hd^-1/2 * log2 e), Vt = V transposed. */
-int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* Vt, void* O, int64_t ldo, int32_t B,
+/* softmax(q k^T) v per (clip, head); QK rows hold [q | k] (q pre-scaled by hd^-1/2 * log2 e), V rows (ld = ldv, same row
+ * indexing) hold v; normally all three are columns of one packed q|k|v projection output. */
+int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* V, int64_t ldv, void* O, int64_t ldo, int32_t B,
                          int32_t T, int32_t P, int32_t heads, int32_t d, void* stream);
 
 int32_t wfl_op_layernorm(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,

@@ -59,15 +59,15 @@ def pad_weight(w, bias=None):
 
 
 def gemm(A, a_off, lda, Wp, M, n_valid, P, T, Cout, c_ld, c_lead, c_pitch, bias=None, res=None, ldres=0, alpha=1.0,
-         act=0, glu=0, out_f32=0, Vt=None, vt_n0=0, cin=0, tap_stride=0):
+         act=0, glu=0, out_f32=0, cin=0, tap_stride=0):
     N, K = Wp.shape
     rc = lib().wfl_op_gemm(ptr(A, a_off), lda, cin, tap_stride, ptr(Wp), M, N, K, n_valid, P, T, ptr(Cout), c_ld, c_lead,
-                           c_pitch, ptr(bias), ptr(res), ldres, float(alpha), act, glu, out_f32, ptr(Vt), vt_n0, stream())
+                           c_pitch, ptr(bias), ptr(res), ldres, float(alpha), act, glu, out_f32, stream())
     _lib.check(rc, "wfl_op_gemm")
 
 
-def attention(QK, ldqk, lead, Vt, O, ldo, B, T, P, heads, d):
-    _lib.check(lib().wfl_op_attention(ptr(QK), ldqk, lead, ptr(Vt), ptr(O), ldo, B, T, P, heads, d, stream()), "wfl_op_attention")
+def attention(QK, ldqk, lead, V, v_off, ldv, O, ldo, B, T, P, heads, d):
+    _lib.check(lib().wfl_op_attention(ptr(QK), ldqk, lead, ptr(V, v_off), ldv, ptr(O), ldo, B, T, P, heads, d, stream()), "wfl_op_attention")
 
 
 def layernorm(x, y, g, b, eps, lead, B, P, T, Cn):

@@ -128,7 +128,7 @@ def test_gemm_glu():
 @pytest.mark.parametrize("d,heads,T", [(64, 2, 100), (128, 2, 257), (512, 8, 1500), (512, 2, 300), (768, 2, 300), (1024, 2, 200),
                                        (1280, 2, 150)])
 def test_qkv_projection_and_attention(d, heads, T):
-    """packed q|k|v GEMM (V written transposed) + flash attention vs softmax(q k^T / sqrt(hd)) v."""
+    """packed q|k|v GEMM + flash attention (V read row-major through the transposing LDS read) vs softmax(q k^T / sqrt(hd)) v."""
     B = 2
     hd = d // heads
     x0 = _rand(B, T, d, seed=20)
@@ -138,28 +138,26 @@ def test_qkv_projection_and_attention(d, heads, T):
     wq = w.clone(); bq = bias.clone()
     wq[:d] *= qs; bq[:d] *= qs
     wp, bp = G.pad_weight(wq, bq)
-    qk = G.Rows(B, T, 2 * d)
-    vt = torch.zeros(B * d * a.P + 256, dtype=torch.bfloat16, device="cuda")
-    G.gemm(a.buf, a.lead * d, d, wp, B * a.P, 3 * d, a.P, T, qk.buf, 2 * d, qk.lead, qk.P, bias=bp, Vt=vt, vt_n0=2 * d)
+    qkv = G.Rows(B, T, 3 * d)
+    G.gemm(a.buf, a.lead * d, d, wp, B * a.P, 3 * d, a.P, T, qkv.buf, 3 * d, qkv.lead, qkv.P, bias=bp)
     torch.cuda.synchronize()
     proj = a.get() @ _bf(wq).T + bq
-    _close(qk.get(), proj[..., :2 * d], what="q|k")
-    vt_view = vt[:B * d * a.P].view(B, d, a.P).float()
-    _close(vt_view[:, :, :T], proj[..., 2 * d:].transpose(1, 2), what="V^T")
-    assert bool((vt_view[:, :, T:] == 0).all())
+    _close(qkv.get(), proj, what="q|k|v")
+    assert qkv.halo_is_zero()
     o = G.Rows(B, T, d)
-    G.attention(qk.buf, 2 * d, qk.lead, vt, o.buf, d, B, T, a.P, heads, d)
+    G.attention(qkv.buf, 3 * d, qkv.lead, qkv.buf, 2 * d, 3 * d, o.buf, d, B, T, a.P, heads, d)
     torch.cuda.synchronize()
-    q = qk.get()[..., :d].view(B, T, heads, hd).transpose(1, 2) / math.log2(math.e)
-    k = qk.get()[..., d:].view(B, T, heads, hd).transpose(1, 2)
-    v = vt_view[:, :, :T].transpose(1, 2).reshape(B, T, heads, hd).transpose(1, 2)
+    q = qkv.get()[..., :d].view(B, T, heads, hd).transpose(1, 2) / math.log2(math.e)
+    k = qkv.get()[..., d:2 * d].view(B, T, heads, hd).transpose(1, 2)
+    v = qkv.get()[..., 2 * d:].view(B, T, heads, hd).transpose(1, 2)
     ref = (torch.softmax(q @ k.transpose(2, 3), -1) @ v).transpose(1, 2).reshape(B, T, d)
     _close(o.get(), ref, rtol=2e-2, atol=1e-2, what="attention")
     assert o.halo_is_zero()
 
 
 def test_attention_peaked_softmax():
-    """a query row that matches one late key with a huge score (forces the online-softmax rescale path)."""
+    """a query row that matches one late key with a huge score (forces the online-softmax rescale path); V in its own
+    buffer (ldv != ldqk)."""
     B, T, d, heads = 1, 200, 64, 1
     q = _rand(B, T, d, seed=23) * 0.1
     k = _rand(B, T, d, seed=24) * 0.1
@@ -167,11 +165,9 @@ def test_attention_peaked_softmax():
     k[0, 170] = 3.0
     q[0, 5] = 3.0                       # score(5, 170) ~ 576 in log2 units; everything else ~0
     qk = G.Rows(B, T, 2 * d).set(torch.cat([q, k], -1))
-    P = qk.P
-    vt = torch.zeros(B * d * P + 256, dtype=torch.bfloat16, device="cuda")
-    vt[:B * d * P].view(B, d, P)[:, :, :T] = v.transpose(1, 2).to(torch.bfloat16)
+    vr = G.Rows(B, T, d).set(v)
     o = G.Rows(B, T, d)
-    G.attention(qk.buf, 2 * d, qk.lead, vt, o.buf, d, B, T, P, heads, d)
+    G.attention(qk.buf, 2 * d, qk.lead, vr.buf, 0, d, o.buf, d, B, T, qk.P, heads, d)
     torch.cuda.synchronize()
     s = (_bf(q) @ _bf(k).transpose(1, 2)) * math.log(2.0)
     ref = torch.softmax(s, -1) @ _bf(v)

@@ -3,16 +3,24 @@
 // Conformer block (/root/reference/model.py:26, 42; head_dim = d / conformer_heads = 256 for Whisper-base).
 //
 // One workgroup = 4 waves = one (clip, head, block of query frames); each wave owns QT tiles of 16 query frames.
-// K tiles (64 keys x HD) and V^T tiles (HD x 64 keys; the QKV projection already wrote V transposed) are staged
-// in LDS.  Scores are computed TRANSPOSED, S^T = K . Q^T with MFMA 16x16x32 (A = K rows, B = Q rows), so every
+// K tiles and V tiles (64 keys x HD, both row-major exactly as the packed q|k|v projection wrote them) are staged in
+// LDS.  Scores are computed TRANSPOSED, S^T = K . Q^T with MFMA 16x16x32 (A = K rows, B = Q rows), so every
 // lane holds scores of ONE query frame (column lane&15) and the row max/sum need only two cross-lane steps; the
-// S^T accumulators are then already laid out as the B operand of O^T = V^T . P^T (key order inside a 32-key
-// k-step is permuted identically for P and for the V^T fragment reads), so P never touches LDS.
+// S^T accumulators are then already laid out as the B operand of O^T = V^T . P^T, whose A operand (V^T fragments:
+// 8 keys of one channel per lane) comes out of the row-major V tile by ds_read_b64_tr_b16, the hardware transposing
+// read (key order inside a 32-key k-step is permuted identically for P and for the V reads), so neither P nor a
+// transposed copy of V ever exists.
 // q is pre-scaled by head_dim^-1/2 * log2(e) at weight-pack time, so the softmax is exp2(s - max).
 #include "common.h"
 
 #define KT 64          // keys per tile
-#define VPITCH 136     // bytes per V^T LDS row (64 keys * 2 + 8 pad): conflict-free ds_read_b64
+// V tile rows are HD*2 + 32 bytes apart: the 8 key rows x 32 bytes one 32-lane half of a ds_read_b64_tr_b16 touches then
+// fall into 8 different 32-byte windows of the 256-byte bank row (conflict-free for HD = 32 .. 640).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
+static __device__ __forceinline__ bf16x4 ds_read_tr(const char* p) {
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)p));
+}
 
 template <int HD>
 static __device__ __forceinline__ int k_swz(int row) {
@@ -26,10 +34,10 @@ template <int HD, int QT, bool PREFETCH, bool BIAS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                       // [KT][HD] bf16, 16-byte chunks XOR-swizzled
-  char* Vs = smem + KT * HD * 2;         // [HD][VPITCH]
+  char* Vs = smem + KT * HD * 2;         // [KT][VPITCH]
+  constexpr int VPITCH = HD * 2 + 32;
   constexpr int CPR = HD / 8;
-  constexpr int KCH = KT * CPR / 256;    // K chunks per thread per tile
-  constexpr int VCH = HD * 8 / 256;      // V^T chunks per thread per tile
+  constexpr int KCH = KT * CPR / 256;    // K (and V) chunks per thread per tile
   constexpr int KS = HD / 32;            // k-steps over head_dim
   constexpr int DT = HD / 16;            // output channel tiles
 
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   const int q0 = qb * (4 * QT * 16) + wid * (QT * 16);
   const long row0 = p.lead + (long)b * p.P;
   const bf16_t* Kg = p.QK + p.d + h * HD;                 // + row * ldqk
-  const bf16_t* Vg = p.Vt + ((long)b * p.d + h * HD) * p.P;
+  const bf16_t* Vg = p.V + h * HD;                        // + row * ldv
 
   // ---- Q fragments (B operand): lane -> query frame q0 + 16*qt + c, channels 32*ks + 8*g .. +8
   bf16x8 qf[QT][KS];
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 
   const int ntiles = (p.T + KT - 1) / KT;
-  bf16x8 kreg[KCH], vreg[VCH];
+  bf16x8 kreg[KCH], vreg[KCH];
 
   auto load_tile = [&](int kt) {
 #pragma unroll
@@ -83,12 +91,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       const int ch = tid + 256 * i;
       const int r = ch / CPR, cc = ch % CPR;
       kreg[i] = *(const bf16x8*)(Kg + (row0 + kt * KT + r) * p.ldqk + cc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-      const int ch = tid + 256 * i;
-      const int r = ch >> 3, cc = ch & 7;
-      vreg[i] = *(const bf16x8*)(Vg + (long)r * p.P + kt * KT + cc * 8);
+      vreg[i] = *(const bf16x8*)(Vg + (row0 + kt * KT + r) * p.ldv + cc * 8);
     }
   };
   auto store_tile = [&]() {
@@ -97,15 +100,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       const int ch = tid + 256 * i;
       const int r = ch / CPR, cc = ch % CPR;
       *(bf16x8*)(Ks + r * (HD * 2) + ((cc ^ k_swz<HD>(r)) << 4)) = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-      const int ch = tid + 256 * i;
-      const int r = ch >> 3, cc = ch & 7;
-      const bf16x4 lo = {vreg[i][0], vreg[i][1], vreg[i][2], vreg[i][3]};
-      const bf16x4 hi = {vreg[i][4], vreg[i][5], vreg[i][6], vreg[i][7]};
-      *(bf16x4*)(Vs + r * VPITCH + cc * 16) = lo;
-      *(bf16x4*)(Vs + r * VPITCH + cc * 16 + 8) = hi;
+      *(bf16x8*)(Vs + r * VPITCH + cc * 16) = vreg[i];
     }
   };
 
@@ -202,14 +197,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       }
     }
 
-    // ---- O^T += V^T . P^T : k-slot 8g+j of k-step s2 is key 32*s2 + 4g + j (j<4) / 32*s2 + 16 + 4g + j-4
+    // ---- O^T += V^T . P^T : k-slot 8g+j of k-step s2 is key 32*s2 + 4g + j (j<4) / 32*s2 + 16 + 4g + j-4.
+    // Transposing read: lane 4q+pp of a 16-lane group addresses key row (block base + q), channels 4pp..4pp+3 and
+    // receives channel (lane & 15) of the block's 4 key rows.
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const char* vp = Vs + (dt * 16 + c) * VPITCH + (32 * s2 + 4 * g) * 2;
-        const bf16x4 lo = *(const bf16x4*)vp;
-        const bf16x4 hi = *(const bf16x4*)(vp + 32);
+        const char* vp = Vs + (32 * s2 + 4 * g + (c >> 2)) * VPITCH + (dt * 16 + 4 * (c & 3)) * 2;
+        const bf16x4 lo = ds_read_tr(vp);
+        const bf16x4 hi = ds_read_tr(vp + 16 * VPITCH);
         const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
@@ -241,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
 template <int HD, int QT, bool PREFETCH, bool BIAS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
-  constexpr int lds = KT * HD * 2 + HD * VPITCH;
+  constexpr int lds = KT * HD * 2 + KT * (HD * 2 + 32);
   auto k = attn_kernel<HD, QT, PREFETCH, BIAS>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -257,7 +254,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
 int wfl_launch_attention_big(const AttnArgs& a, hipStream_t s);   // attention_big.hip: head_dim 384 / 512 / 640
 
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
-  if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldo % 4 || a.T <= 0) return -1;
+  if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldv % 8 || a.ldo % 4 || a.T <= 0 || !a.V) return -1;
   const int hd = a.d / a.heads;
   if (a.bias) {
     if (!a.gate) return -1;

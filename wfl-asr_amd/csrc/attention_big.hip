@@ -1,16 +1,22 @@
 // Flash-style attention for the Conformer block's LARGE heads: head_dim = d / conformer_heads = 384 (Whisper-small),
 // 512 (WavLM-large), 640 (Whisper-large) with the reference's default conformer_heads = 2 (/root/reference/model.py:26,
 // config.yaml:28).  Same algorithm and operand layouts as attention.hip (S^T = K.Q^T, P kept in registers as the B
-// operand of O^T = V^T.P^T, K tile XOR-swizzled, V^T tile padded), but the register budget is spent on the output
+// operand of O^T = V^T.P^T, K tile XOR-swizzled, row-major V tile read through ds_read_b64_tr_b16), but the register budget is spent on the output
 // accumulators (head_dim / 4 VGPRs per lane), so each wave owns ONE 16-query tile, Q fragments are re-read from L2
-// for every key tile instead of living in registers, and head_dim 640 uses 32-key tiles to fit K and V^T in LDS.
+// for every key tile instead of living in registers, and head_dim 640 uses 32-key tiles to fit K and V in LDS.
 #include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4b_t;
+typedef __attribute__((address_space(3))) s16x4b_t* lds_s16x4b_t;
+static __device__ __forceinline__ bf16x4 ds_read_tr_big(const char* p) {
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4b_t)p));
+}
 
 template <int HD, int KTL>
 __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CPR = HD / 8;              // 16-byte chunks per K row (multiple of 16)
-  constexpr int VP = KTL * 2 + 8;          // V^T row pitch in bytes
+  constexpr int VP = HD * 2 + 32;          // V tile row pitch in bytes (see attention.hip)
   constexpr int KS = HD / 32, DT = HD / 16, NKK = KTL / 16, NS2 = KTL / 32;
   char* Ks = smem;
   char* Vs = smem + KTL * HD * 2;
@@ -28,7 +34,7 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
   const int q0 = qb * 64 + wid * 16;
   const long row0 = p.lead + (long)b * p.P;
   const bf16_t* Kg = p.QK + p.d + h * HD;
-  const bf16_t* Vg = p.Vt + ((long)b * p.d + h * HD) * p.P;
+  const bf16_t* Vg = p.V + h * HD;
   int qrow = q0 + c;
   qrow = qrow < p.T ? qrow : p.T - 1;
   const bf16_t* qp = p.QK + (row0 + qrow) * p.ldqk + h * HD + g * 8;
@@ -47,12 +53,9 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
       *(bf16x8*)(Ks + r * (HD * 2) + ((cc ^ (r & 15)) << 4)) = *(const bf16x8*)(Kg + (row0 + kt * KTL + r) * p.ldqk + cc * 8);
     }
 #pragma unroll 4
-    for (int ch = tid; ch < HD * (KTL / 8); ch += 256) {
-      const int r = ch / (KTL / 8), cc = ch - r * (KTL / 8);
-      const bf16x8 v = *(const bf16x8*)(Vg + (long)r * p.P + kt * KTL + cc * 8);
-      const bf16x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-      *(bf16x4*)(Vs + r * VP + cc * 16) = lo;
-      *(bf16x4*)(Vs + r * VP + cc * 16 + 8) = hi;
+    for (int ch = tid; ch < KTL * CPR; ch += 256) {
+      const int r = ch / CPR, cc = ch - r * CPR;
+      *(bf16x8*)(Vs + r * VP + cc * 16) = *(const bf16x8*)(Vg + (row0 + kt * KTL + r) * p.ldv + cc * 8);
     }
     __syncthreads();
 
@@ -111,9 +114,9 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
       for (int s2 = 0; s2 < NS2; ++s2) {
-        const char* vp = Vs + (dt * 16 + c) * VP + (32 * s2 + 4 * g) * 2;
-        const bf16x4 lo = *(const bf16x4*)vp;
-        const bf16x4 hi = *(const bf16x4*)(vp + 32);
+        const char* vp = Vs + (32 * s2 + 4 * g + (c >> 2)) * VP + (dt * 16 + 4 * (c & 3)) * 2;
+        const bf16x4 lo = ds_read_tr_big(vp);
+        const bf16x4 hi = ds_read_tr_big(vp + 16 * VP);
         const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s2], o[dt], 0, 0, 0);
       }
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
 
 template <int HD, int KTL>
 static int launch_big(const AttnArgs& a, hipStream_t s) {
-  constexpr int lds = KTL * HD * 2 + HD * (KTL * 2 + 8);
+  constexpr int lds = KTL * HD * 2 + KTL * (HD * 2 + 32);
   auto k = attn_big_kernel<HD, KTL>;
   static bool attr_set = false;
   if (!attr_set) {

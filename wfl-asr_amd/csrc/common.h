@@ -62,7 +62,8 @@ struct AttnArgs {
   const bf16_t* QK;   // frame rows, ld = ldqk: [q (d) | k (d)] per row, q pre-scaled by hd^-1/2 * log2(e)
   long ldqk;
   long lead;          // row(b,t) = lead + b*P + t
-  const bf16_t* Vt;   // [B][heads*hd][P]
+  const bf16_t* V;    // frame rows, ld = ldv, head h at column h*hd (normally the v columns of the packed q|k|v rows)
+  long ldv;
   bf16_t* O;          // frame rows, ld = ldo, head h at column h*hd
   long ldo;
   int B, T, P, heads, d;

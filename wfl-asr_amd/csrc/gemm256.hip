@@ -109,12 +109,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     else if ((later) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
   } while (0)
+#ifdef WFL_ABL_NOLDS      // diagnostic: fragments are read once (slot 0) and never again
+#define LDW(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = *(const bf16x8*)(smem + w_off + v_ * 1024)
+#define LDX(dst, slot, u0, cnt) _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) dst[u_] = *(const bf16x8*)(smem + x_off + u_ * 1024)
+#define LDW_L(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = fw[v_]
+#define LDX_L(dst, slot, u0, cnt) do { } while (0)
+#else
 #define LDW(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = *(const bf16x8*)(smem + (slot) * ST2 + w_off + v_ * 1024)
 #define LDX(dst, slot, u0, cnt) _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) dst[u_] = *(const bf16x8*)(smem + (slot) * ST2 + x_off + ((u0) + u_) * 1024)
+#define LDW_L LDW
+#define LDX_L LDX
+#endif
+#ifdef WFL_ABL_NOMMA      // diagnostic: keep the fragment reads alive, issue no MFMA
+#define MMA2(fw, fx, u0, cnt)                                                 \
+  _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) asm volatile("" :: "v"(fx[u_]));   \
+  _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) asm volatile("" :: "v"(fw[v_]))
+#else
 #define MMA2(fw, fx, u0, cnt)                                                 \
   _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_)                        \
     _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_)                          \
       acc[(u0) + u_][v_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v_], fx[u_], acc[(u0) + u_][v_], 0, 0, 0)
+#endif
 
   bf16x8 fw[4], fwn[4], fx0[4], fx1[4];
 #pragma unroll
@@ -127,11 +142,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     STAMP2(1);
     LDW(fw, 0);
     LDX(fx0, 0, 0, 4);
+#ifdef WFL_ABL_NOLDS
+    LDX(fx1, 0, 4, MT - 4);
+#endif
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt % NST2;
     LGKM2();
-    LDX(fx1, slot, 4, MT - 4);
+    LDX_L(fx1, slot, 4, MT - 4);
     SB2();
     MMA2(fw, fx0, 0, 4);
     SB2();
@@ -139,11 +157,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
       const int last = (kt + NST2 - 2 < nk - 1) ? kt + NST2 - 2 : nk - 1;
       WAIT2(last - (kt + 1));
       __builtin_amdgcn_s_barrier();
+#ifndef WFL_ABL_NOSTAGE    // diagnostic: no operand traffic inside the K loop
       if (kt + NST2 - 1 < nk) stage((kt + NST2 - 1) % NST2, kt + NST2 - 1);
+#endif
     }
     LGKM2();
-    LDW(fwn, (kt + 1) % NST2);
-    LDX(fx0, (kt + 1) % NST2, 0, 4);
+    LDW_L(fwn, (kt + 1) % NST2);
+    LDX_L(fx0, (kt + 1) % NST2, 0, 4);
     SB2();
     MMA2(fw, fx1, 4, MT - 4);
     SB2();
@@ -155,6 +175,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #undef WAIT2
 #undef LDW
 #undef LDX
+#undef LDW_L
+#undef LDX_L
 #undef MMA2
 
   // ------------------------------------------------------------------ epilogue: two half-blocks through LDS

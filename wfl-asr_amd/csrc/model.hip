@@ -684,7 +684,7 @@ struct Plan {
   int nlev, Tl[8], Pl[8], leadl[8];
   long Rl[8];
   // byte offsets
-  long mel, c1, X, Y, ATT, QK, VT, FF, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
+  long mel, c1, X, Y, ATT, QK, FF, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
   long FA, FB, XG, gate, rtab, wstats, cstats, total;
 };
 
@@ -741,8 +741,7 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
   p.X = take(p.R * p.d * 2);
   p.Y = take(p.R * p.d * 2);
   p.ATT = take(p.R * p.d * 2);
-  p.QK = take(p.R * 2 * p.d * 2);
-  p.VT = take(((long)B * p.d * p.P + 256) * 2);
+  p.QK = take(p.R * 3 * p.d * 2);                   // packed q | k | v rows
   p.FF = take(p.R * p.ffw * 2);
   p.enc2 = take(p.R * p.d * 2);
   p.clipmax = take((long)B * 4);
@@ -784,7 +783,7 @@ struct Runner {
 
   void gemm(const bf16_t* A, long lda, const Lin& W, int M, int P, int T, void* C, long ldc, long c_lead, int c_pitch,
             int act = WFL_ACT_NONE, const bf16_t* res = nullptr, long ldres = 0, float alpha = 1.f, int cin = 0,
-            long tap_stride = 0, bool glu = false, bool out_f32 = false, bf16_t* Vt = nullptr, int vt_n0 = 0,
+            long tap_stride = 0, bool glu = false, bool out_f32 = false,
             const bf16_t* pos = nullptr, long ldpos = 0, const float* clip_bias = nullptr, const int* clip_idx = nullptr,
             int clip_ld = 0) {
     if (rc) return;
@@ -798,7 +797,6 @@ struct Runner {
     g.res = res; g.ldres = ldres; g.alpha = alpha;
     g.pos = pos; g.ldpos = ldpos;
     g.act = act; g.glu = glu ? 1 : 0; g.out_f32 = out_f32 ? 1 : 0;
-    g.Vt = Vt; g.vt_n0 = vt_n0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof_on) {
       if (m->prof_used >= m->prof.ev.size()) {
@@ -813,7 +811,7 @@ struct Runner {
     const int r = wfl_launch_gemm(g, s);
     if (m->prof_on) {
       (void)hipEventRecord(e1, s);
-      const int key = (act & 7) | (glu ? 8 : 0) | (out_f32 ? 16 : 0) | (Vt ? 32 : 0);
+      const int key = (act & 7) | (glu ? 8 : 0) | (out_f32 ? 16 : 0);
       m->prof.key.push_back(key);
       m->prof.launches[key] += 1;
       m->prof.flops[key] += 2.0 * (double)(M / P) * T * (double)W.n_valid * (double)W.K;
@@ -831,7 +829,7 @@ struct Runner {
     if (rc) return;
     AttnArgs a{};
     a.bias = bias; a.gate = gate;
-    a.QK = buf(p.QK); a.ldqk = 2 * p.d; a.lead = p.lead; a.Vt = buf(p.VT); a.O = buf(p.ATT); a.ldo = p.d;
+    a.QK = buf(p.QK); a.ldqk = 3 * p.d; a.lead = p.lead; a.V = buf(p.QK) + 2 * p.d; a.ldv = 3 * p.d; a.O = buf(p.ATT); a.ldo = p.d;
     a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = p.d;
     const int r = wfl_launch_attention(a, s);
     if (r) rc = fail(r, "attention launch failed (" + std::to_string(r) + "; head_dim " + std::to_string(p.d / heads) + ")");
@@ -897,14 +895,14 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
   if (workspace_bytes < p.total) return fail(-1, "wfl_forward: workspace too small");
   const int d = p.d;
   const long Mrows = (long)B * p.P;
-  bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *VT = R.buf(p.VT), *FF = R.buf(p.FF);
+  bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *FF = R.buf(p.FF);
 
   if (p.T <= 0) return fail(-1, "wfl_forward: clip too short for the encoder");
   // halos of every frame-row buffer (cheap; keeps the layout invariant independent of the workspace's history)
   R.zero_add(p.X, d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.Y, d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.ATT, d, p.lead, p.P, p.T, p.tail);
-  R.zero_add(p.QK, 2 * d, p.lead, p.P, p.T, p.tail);
+  R.zero_add(p.QK, 3 * d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
   if (a.encoder_type == WFL_ENC_WHISPER) {
     R.zero_add(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
@@ -923,12 +921,11 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     R.gemm(mel + (long)(p.lead2 - 1) * a.n_mels, a.n_mels, m->conv1, B * p.P2, p.P2, p.T2, c1, d, p.lead2, p.P2, WFL_ACT_GELU);
     // conv2 k3 s2 p1: frame t reads c1 rows 2t-1..2t+1; pitch(c1) = 2 * pitch(X) makes it one flat GEMM with lda = 2d
     R.gemm(c1 + (long)(p.lead2 - 1) * d, 2 * d, m->conv2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0,
-           1.f, 0, 0, false, false, nullptr, 0, m->pos, d);
+           1.f, 0, 0, false, false, m->pos, d);
     for (int i = 0; i < a.enc_layers; ++i) {
       const EncLayer& L_ = m->enc[i];
       R.ln(X, Y, L_.ln1);
-      R.gemm(Y + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 2 * d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
-             false, false, VT, 2 * d);
+      R.gemm(Y + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
       R.attn(a.enc_heads);
       R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
       R.ln(X, Y, L_.ln2);
@@ -1009,8 +1006,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
       if (R.rc) break;
       int r = wfl_launch_relpos_gate(A_in, d, p.lead, B, p.P, p.T, a.enc_heads, hd, L_.w8, L_.b8, L_.cst, gate, R.s);
       if (r) return fail(r, "relpos_gate launch failed");
-      R.gemm(A_in + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 2 * d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
-             false, false, VT, 2 * d);
+      R.gemm(A_in + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
       R.attn(a.enc_heads, rtab, gate);
       if (stable) {
         // x = x + attn; x = x + FFN(LN(x))
@@ -1063,7 +1059,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
         idx = lang_dev;
       }
       R.gemm(ENC + (long)p.lead * d, d, m->lang, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
-             false, false, nullptr, 0, nullptr, 0, m->lang_table, idx, d);
+             false, false, nullptr, 0, m->lang_table, idx, d);
       H = X; S = Y;
     }
     if (a.enable_bilstm) {
@@ -1089,8 +1085,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
       R.gemm(S + (long)p.lead * d, d, C.ff1_a, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff1_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
       // x = LN1(x + MHA(x))
-      R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 2 * d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
-             false, false, VT, 2 * d);
+      R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
       R.attn(a.conformer_heads);
       R.gemm(ATT + (long)p.lead * d, d, C.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
       R.ln(S, H, C.ln1);
@@ -1171,21 +1166,20 @@ int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_
 int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride, const void* W, int32_t M, int32_t N,
                     int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead, int32_t c_pitch,
                     const float* bias, const void* res, int64_t ldres, float alpha, int32_t act, int32_t glu,
-                    int32_t out_f32, void* Vt, int32_t vt_n0, void* stream) {
+                    int32_t out_f32, void* stream) {
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.cin = cin > 0 ? cin : K; g.tap_stride = tap_stride;
   g.W = (const bf16_t*)W; g.M = M; g.N = N; g.K = K; g.n_valid = n_valid; g.P = P; g.T = T;
   g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch; g.bias = bias;
   g.res = (const bf16_t*)res; g.ldres = ldres; g.alpha = alpha; g.act = act; g.glu = glu; g.out_f32 = out_f32;
-  g.Vt = (bf16_t*)Vt; g.vt_n0 = vt_n0;
   const int r = wfl_launch_gemm(g, (hipStream_t)stream);
   return r ? fail(r, "wfl_op_gemm: invalid arguments or launch failure (" + std::to_string(r) + ")") : 0;
 }
 
-int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* Vt, void* O, int64_t ldo, int32_t B, int32_t T,
+int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* V, int64_t ldv, void* O, int64_t ldo, int32_t B, int32_t T,
                          int32_t P, int32_t heads, int32_t d, void* stream) {
   AttnArgs a{};
-  a.QK = (const bf16_t*)QK; a.ldqk = ldqk; a.lead = lead; a.Vt = (const bf16_t*)Vt; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.QK = (const bf16_t*)QK; a.ldqk = ldqk; a.lead = lead; a.V = (const bf16_t*)V; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
   a.B = B; a.T = T; a.P = P; a.heads = heads; a.d = d;
   const int r = wfl_launch_attention(a, (hipStream_t)stream);
   return r ? fail(r, "wfl_op_attention: invalid arguments, unsupported head_dim or launch failure (" + std::to_string(r) + ")") : 0;
