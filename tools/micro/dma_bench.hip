@@ -1,0 +1,131 @@
+// Diagnostic (not product): L2 -> LDS DMA throughput per CU for the access shapes a GEMM operand tile can take.
+// Each block (512 threads, 1 per CU) streams its own A-panel (rows x K bf16, row pitch LDA bytes) and a shared W panel
+// through a 4-deep LDS ring with counted vmcnt, optionally with MFMAs in flight (clock under matrix load).
+//   shape RB = bytes per row per wave-instruction: 64 (16 rows x 64 B), 128 (8 x 128), 256 (4 x 256)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int RB, int MFMA_PER_STEP>
+__global__ __launch_bounds__(512) void dma_kernel(const char* A, long lda, const char* W, long ldw, int rowsA, int rowsW, int ksteps,
+                                                  int kbytes_per_step, int share, int nst, float* sink, unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int LPR = RB / 16;            // lanes per row
+  constexpr int RPI = 64 / LPR;           // rows per instruction
+  // per step the block moves (rowsA + rowsW) * kbytes_per_step bytes; each wave instruction moves 1 KiB
+  const int instrA = rowsA * kbytes_per_step / 1024, instrW = rowsW * kbytes_per_step / 1024;
+  const int per_wave = (instrA + instrW) / 8;
+  const int stage_bytes = (rowsA + rowsW) * kbytes_per_step;
+  const char* Ab = A + (long)(blockIdx.x / share) * rowsA * lda;
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa, fb;
+  for (int i = 0; i < 8; ++i) { fa[i] = (__bf16)(0.01f * (lane + i)); fb[i] = (__bf16)(0.02f * (lane - i)); }
+  auto issue = [&](int step) {
+    char* lbase = smem + (step % nst) * stage_bytes;
+    for (int j = 0; j < per_wave; ++j) {
+      const int idx = wid * per_wave + j;            // instruction index within the stage
+      const char* src;
+      if (idx < instrA) {
+        // instruction covers RPI rows x RB bytes; the RB-byte pieces of a row within a step are consecutive instructions
+        const int pieces = kbytes_per_step / RB;     // per row
+        const int rg = idx / pieces, pc = idx % pieces;
+        const int row = rg * RPI + lane / LPR;
+        src = Ab + (long)row * lda + (long)step * kbytes_per_step + pc * RB + (lane % LPR) * 16;
+      } else {
+        const int i2 = idx - instrA;
+        const int pieces = kbytes_per_step / RB;
+        const int rg = i2 / pieces, pc = i2 % pieces;
+        const int row = rg * RPI + lane / LPR;
+        src = W + (long)row * ldw + (long)step * kbytes_per_step + pc * RB + (lane % LPR) * 16;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + idx * 1024), 16, 0, 0);
+    }
+  };
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int s = 0; s < nst - 1; ++s) issue(s);
+  for (int s = 0; s < ksteps; ++s) {
+    if (s + nst - 1 < ksteps) issue(s + nst - 1);
+    // leave nst-1 stages in flight: per_wave ops each
+    const int fl = per_wave * (nst - 1);
+    if (fl >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (fl >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (fl >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (fl >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (fl >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (fl >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (fl >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MFMA_PER_STEP; ++i)
+      acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i & 7], 0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0.f;
+  for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  r += smem[tid * 4];
+  if (r == 123.456f) sink[0] = r;
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int RB, int MM>
+static void run(const char* name, const char* A, long lda, const char* W, long ldw, int rowsA, int rowsW, int ksteps, int kb, int share, int nst,
+                float* sink, unsigned long long* cyc) {
+  const int lds = nst * (rowsA + rowsW) * kb;
+  if (lds > 160 * 1024) { printf("%s: LDS too large\n", name); return; }
+  auto k = dma_kernel<RB, MM>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, A, lda, W, ldw, rowsA, rowsW, ksteps, kb, share, nst, sink, cyc);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, A, lda, W, ldw, rowsA, rowsW, ksteps, kb, share, nst, sink, cyc);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(256);
+  hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+  double avg = 0;
+  for (auto v : h) avg += v;
+  avg /= 256;
+  const double us = ms * 1e3 / reps;
+  const double bytes = (double)(rowsA + rowsW) * kb * ksteps;
+  printf("%-34s share=%3d nst=%d RB=%3d mfma/step=%2d  %8.1f us  %6.1f GB/s/CU  %6.2f TB/s chip  %5.1f B/clk/CU  (%.0f cyc/step, clk %.2f GHz)\n", name, share, nst, RB, MM, us,
+         bytes / us / 1e3, bytes * 256 / us / 1e6, bytes / avg, avg / ksteps, avg / us / 1e3);
+}
+
+int main() {
+  const long lda = 1024, ldw = 4096;          // A: [24576+][512] bf16; W: [256][2048] bf16
+  const int rowsA = 256, rowsW = 256, ksteps = 64;
+  char *A, *W; float* sink; unsigned long long* cyc;
+  hipMalloc(&A, 256L * rowsA * lda + (1 << 20));
+  hipMalloc(&W, 256L * 8192 + (1 << 20));
+  hipMalloc(&sink, 64); hipMalloc(&cyc, 256 * 8);
+  hipMemset(A, 1, 256L * rowsA * lda); hipMemset(W, 1, 256L * 8192);
+  // kb = K bytes per row per step: 64 (BK=32) for RB=64; 128 (BK=64) for RB=64/128
+  // lda = 1024 B means K = 512 -> with kb=64 only 16 steps are distinct; wrap by using ksteps=16 per pass x4 via modulo is not
+  // done: A rows are 1024 B, so ksteps*kb must be <= 1024 for A. Use W/A panels with K=2048 (lda 4096) instead.
+  hipFree(A);
+  hipMalloc(&A, 256L * rowsA * 8192 + (1 << 20));
+  hipMemset(A, 1, 256L * rowsA * 8192);
+  const long lda2 = 4096;
+  for (long ld : {1024L, 1152L, 2048L, 2176L, 4096L, 4224L, 8192L}) {
+    printf("---- row pitch %ld bytes (A and W)\n", ld);
+    const int ks32 = (int)(ld >= 4096 ? 64 : ld / 64 - (ld % 1024 ? 2 : 0)), ks64 = ks32 / 2;
+    run<64, 0>("BK32 16x64B", A, ld, W, ld, 256, 256, ks32, 64, 2, 4, sink, cyc);
+    run<128, 0>("BK64 8x128B", A, ld, W, ld, 256, 256, ks64, 128, 2, 2, sink, cyc);
+    run<64, 32>("BK32 16x64B + 32 mfma", A, ld, W, ld, 256, 256, ks32, 64, 2, 4, sink, cyc);
+  }
+  return 0;
+}

@@ -71,19 +71,19 @@ struct AttnArgs {
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
 };
 
-// exact-erf GELU (nn.GELU() default / HF "gelu") with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below
-// the bf16 rounding of the stored result): 1 rcp + 1 exp + 6 FMA instead of libm erff's long branchy polynomial
-// (which cost 8.6 us of a 20 us fc1 tile: tools/gemm_diag.py).
+// erf GELU (nn.GELU() default / HF "gelu"):  gelu(x) = max(x, 0) - |x| * Phi(-|x|),  Phi(-t) = 0.5 * erfc(t / sqrt 2).
+// log2 Phi(-t) is smooth and nearly quadratic, so Phi(-t) = exp2(q(t)) with q a degree-5 minimax fit on [0, 6] weighted
+// by the error it causes in gelu (tools/fit_gelu.py): |gelu error| <= 6.4e-7 over all x in fp32 (the bf16 rounding of the
+// stored value is ~4e-3 relative), q -> -inf beyond the fit range so large |x| need no clamp.  5 FMA + 1 v_exp + 3 VALU,
+// against 2 transcendentals + 13 VALU for the Abramowitz-Stegun 7.1.26 form used before (9 us of a 27 us fc1 tile).
 static __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(z)
-  const float h = 0.5f * x * e;                                                    // x >= 0: x - h ; x < 0: h
-  return x >= 0.f ? x - h : h;
+  const float t = fabsf(x);
+  float q = fmaf(-4.732937668e-04f, t, 7.084457669e-03f);
+  q = fmaf(q, t, -5.182715505e-02f);
+  q = fmaf(q, t, -4.599926770e-01f);
+  q = fmaf(q, t, -1.150787711e+00f);
+  q = fmaf(q, t, -1.000037670e+00f);
+  return fmaxf(x, 0.f) - t * __builtin_amdgcn_exp2f(q);
 }
 static __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

@@ -10,10 +10,9 @@
 // accumulators (128 VGPRs).  Operand tiles arrive by global_load_lds_dwordx4 into a 4-deep ring of 32 KiB stages
 // (counted vmcnt, raw s_barrier).  Rows are 64 bytes (32 bf16), so four rows share a 256-byte bank row; the 16-byte
 // chunk swizzle chunk' = chunk ^ ((-(row >> 2)) & 3) makes every ds_read_b128 lane group hit 16 distinct slots.
-// The K step is split in two halves that share the weight fragments:
-//     read X[4:8](kt) | 16 MFMA on X[0:4](kt)
-//     wait tile kt+1 ; s_barrier ; prefetch tile kt+3
-//     read W(kt+1), X[0:4](kt+1) | 16 MFMA on X[4:8](kt)
+// K loop = two-group ping-pong (see the comment at the loop): measured 10-12 % faster than running all eight waves in
+// lock step, and tools/gemm_lab.py's ablations show what is left: MFMA alone 0.40 us per 32-deep step, operand DMA alone
+// 0.50 us (the L2 -> LDS limit of ~65 GB/s per CU), both together ~0.61-0.65 us.
 // The epilogue leaves through LDS in two 128-row halves (fp32, pitch 260) exactly like gemm.hip's.
 #include "common.h"
 #include <cstdlib>
@@ -63,27 +62,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
   // staging: wave w issues loads i = 0,1 for each operand; load covers tile rows (2w+i)*16 .. +16,
   // lane l -> row (l >> 2), physical chunk (l & 3), logical chunk = phys ^ swz2(row)
+  // The 192-row block stages only the 12 frame row groups it computes: waves 0-3 load two each (rows 0..127), waves 4-7
+  // one each (rows 128..191) -- 28 KiB per K step instead of 32 (the K loop is bound by L2 -> LDS bytes).
+  const bool two_x = MT == 8 || wid < 4;
+  const int xg0 = (MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4);
   const bf16_t* a_src[2];
   const bf16_t* w_src[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int row = (wid * 2 + i) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ swz2(row);
-    int am = m0 + row;
+    const int wrow = (wid * 2 + i) * 16 + (lane >> 2);
+    const int xrow = (xg0 + i) * 16 + (lane >> 2);
+    int am = m0 + xrow;
     am = am < p.M ? am : p.M - 1;
-    a_src[i] = p.A + (long)am * p.lda + chunk * 8;
-    w_src[i] = p.W + (long)(n0 + row) * p.K + chunk * 8;
+    a_src[i] = p.A + (long)am * p.lda + ((lane & 3) ^ swz2(xrow)) * 8;
+    w_src[i] = p.W + (long)(n0 + wrow) * p.K + ((lane & 3) ^ swz2(wrow)) * 8;
   }
   const int nk = p.K / BK2;
   auto stage = [&](int buf, int kt) {
     const int k0 = kt * BK2;
     const int tap = k0 / p.cin;
     const long koff = (long)tap * p.tap_stride + (k0 - tap * p.cin);
-    char* base = smem + buf * ST2 + wid * 2048;
+    char* base = smem + buf * ST2;
+    glds16b(a_src[0] + koff, base + xg0 * 1024);
+    if (two_x) glds16b(a_src[1] + koff, base + xg0 * 1024 + 1024);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16b(a_src[i] + koff, base + i * 1024);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16b(w_src[i] + k0, base + 256 * BK2 * 2 + i * 1024);
+    for (int i = 0; i < 2; ++i) glds16b(w_src[i] + k0, base + 256 * BK2 * 2 + wid * 2048 + i * 1024);
   };
 
   const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz2(lane & 15)) << 4);
@@ -105,21 +108,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #define LGKM2() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define WAIT2(later)                                                          \
   do {                                                                        \
-    if ((later) >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
-    else if ((later) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+    if (two_x) {                                                              \
+      if ((later) >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      \
+      else if ((later) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+    } else {                                                                  \
+      if ((later) >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      \
+      else if ((later) == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+    }                                                                         \
   } while (0)
-#ifdef WFL_ABL_NOLDS      // diagnostic: fragments are read once (slot 0) and never again
-#define LDW(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = *(const bf16x8*)(smem + w_off + v_ * 1024)
-#define LDX(dst, slot, u0, cnt) _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) dst[u_] = *(const bf16x8*)(smem + x_off + u_ * 1024)
-#define LDW_L(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = fw[v_]
-#define LDX_L(dst, slot, u0, cnt) do { } while (0)
-#else
 #define LDW(dst, slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) dst[v_] = *(const bf16x8*)(smem + (slot) * ST2 + w_off + v_ * 1024)
 #define LDX(dst, slot, u0, cnt) _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) dst[u_] = *(const bf16x8*)(smem + (slot) * ST2 + x_off + ((u0) + u_) * 1024)
-#define LDW_L LDW
-#define LDX_L LDX
-#endif
 #ifdef WFL_ABL_NOMMA      // diagnostic: keep the fragment reads alive, issue no MFMA
 #define MMA2(fw, fx, u0, cnt)                                                 \
   _Pragma("unroll") for (int u_ = 0; u_ < (cnt); ++u_) asm volatile("" :: "v"(fx[u_]));   \
@@ -131,7 +131,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
       acc[(u0) + u_][v_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v_], fx[u_], acc[(u0) + u_][v_], 0, 0, 0)
 #endif
 
-  bf16x8 fw[4], fwn[4], fx0[4], fx1[4];
+  // Ping-pong K loop: the two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) run the same program one barrier
+  // apart, so that while one group issues its LDS reads + LDS-DMA for a K step ("L slot") the other owns the matrix
+  // pipe ("C slot").  Barrier b(j) ends slot j-1:
+  //     group 0:      L(0) b1 C(0) b2 L(1) b3 C(1) ...          group 1:   b1 L(0) b2 C(0) b3 L(1) ...
+  // Stage kt+1 becomes readable at b(2kt+2): group 0 retires its own DMA for it at the end of C(kt), group 1 at the end
+  // of L(kt), both just before that barrier.  Stage kt+3 reuses the ring slot of stage kt-1, whose last reads (group 1's
+  // L(kt-1)) are drained (lgkmcnt(0)) before b(2kt); it is issued after b(2kt) (group 0) / b(2kt+1) (group 1).
+  const int grp = wid >> 2;
+  bf16x8 fw[4], fx[MT];
 #pragma unroll
   for (int t = 0; t < NST2 - 1; ++t)
     if (t < nk) stage(t, t);
@@ -140,43 +148,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     WAIT2(later);
     __builtin_amdgcn_s_barrier();
     STAMP2(1);
-    LDW(fw, 0);
-    LDX(fx0, 0, 0, 4);
-#ifdef WFL_ABL_NOLDS
-    LDX(fx1, 0, 4, MT - 4);
-#endif
+    if (grp) __builtin_amdgcn_s_barrier();
   }
+#define WAITNEXT()                                                                         \
+  do {                                                                                     \
+    if (kt + 1 < nk) { const int yl = (kt + 3 < nk ? kt + 3 : nk - 1) - (kt + 1); WAIT2(yl); } \
+  } while (0)
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt % NST2;
-    LGKM2();
-    LDX_L(fx1, slot, 4, MT - 4);
-    SB2();
-    MMA2(fw, fx0, 0, 4);
-    SB2();
-    {
-      const int last = (kt + NST2 - 2 < nk - 1) ? kt + NST2 - 2 : nk - 1;
-      WAIT2(last - (kt + 1));
-      __builtin_amdgcn_s_barrier();
-#ifndef WFL_ABL_NOSTAGE    // diagnostic: no operand traffic inside the K loop
-      if (kt + NST2 - 1 < nk) stage((kt + NST2 - 1) % NST2, kt + NST2 - 1);
+    // ---- L slot
+    LDW(fw, slot);
+    LDX(fx, slot, 0, MT);
+#ifndef WFL_ABL_NOSTAGE
+    if (kt + NST2 - 1 < nk) stage((kt + NST2 - 1) % NST2, kt + NST2 - 1);
 #endif
-    }
+    if (grp) WAITNEXT();
     LGKM2();
-    LDW_L(fwn, (kt + 1) % NST2);
-    LDX_L(fx0, (kt + 1) % NST2, 0, 4);
+    __builtin_amdgcn_s_barrier();
     SB2();
-    MMA2(fw, fx1, 4, MT - 4);
+    // ---- C slot
+    MMA2(fw, fx, 0, MT);
     SB2();
-#pragma unroll
-    for (int v = 0; v < 4; ++v) fw[v] = fwn[v];
+    if (!grp) WAITNEXT();
+    if (!(grp && kt == nk - 1)) __builtin_amdgcn_s_barrier();
+    SB2();
   }
+#undef WAITNEXT
 #undef SB2
 #undef LGKM2
 #undef WAIT2
 #undef LDW
 #undef LDX
-#undef LDW_L
-#undef LDX_L
 #undef MMA2
 
   // ------------------------------------------------------------------ epilogue: two half-blocks through LDS
