@@ -129,6 +129,13 @@ int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride,
                     int32_t c_pitch, const float* bias, const void* res, int64_t ldres, float alpha, int32_t act,
                     int32_t glu, int32_t out_f32, void* stream);
 
+/* LayerNorm folded into the GEMM that consumes it (HF modeling_whisper.py:384-385, 401-402; model.py:18, 45):
+ *   C = act( rstd_m * (A W'^T - mean_m * ln_s) + bias ),  W' = gamma o W (bf16), ln_s[n] = sum_k W'[n][k], bias = b + W beta;
+ * mean / rstd are the statistics of row m of A over its K columns, computed inside the kernel.  M >= 2048, N % 256 == 0. */
+int32_t wfl_op_gemm_ln(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, int32_t n_valid, int32_t P,
+                       int32_t T, void* C, int64_t ldc, int64_t c_lead, int32_t c_pitch, const float* bias, const float* ln_s,
+                       float ln_eps, int32_t act, void* stream);
+
 /* softmax(q k^T) v per (clip, head); QK rows hold [q | k] (q pre-scaled by hd^-1/2 * log2 e), V rows (ld = ldv, same row
  * indexing) hold v; normally all three are columns of one packed q|k|v projection output. */
 int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* V, int64_t ldv, void* O, int64_t ldo, int32_t B,

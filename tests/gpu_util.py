@@ -66,6 +66,13 @@ def gemm(A, a_off, lda, Wp, M, n_valid, P, T, Cout, c_ld, c_lead, c_pitch, bias=
     _lib.check(rc, "wfl_op_gemm")
 
 
+def gemm_ln(A, a_off, lda, Wp, M, n_valid, P, T, Cout, c_ld, c_lead, c_pitch, bias, ln_s, eps=1e-5, act=0):
+    N, K = Wp.shape
+    rc = lib().wfl_op_gemm_ln(ptr(A, a_off), lda, ptr(Wp), M, N, K, n_valid, P, T, ptr(Cout), c_ld, c_lead, c_pitch, ptr(bias),
+                              ptr(ln_s), float(eps), act, stream())
+    _lib.check(rc, "wfl_op_gemm_ln")
+
+
 def attention(QK, ldqk, lead, V, v_off, ldv, O, ldo, B, T, P, heads, d):
     _lib.check(lib().wfl_op_attention(ptr(QK), ldqk, lead, ptr(V, v_off), ldv, ptr(O), ldo, B, T, P, heads, d, stream()), "wfl_op_attention")
 

@@ -293,3 +293,67 @@ def test_gemm256_both_block_heights():
                             "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, (bm, r.stdout[-3000:])
+
+
+# ---- the persistent streaming kernel (gemm_stream.hip): several tiles per workgroup, register epilogue, folded LayerNorm
+
+@pytest.mark.parametrize("B,T,K,N,act,res", [(16, 1500, 512, 1536, 0, False), (16, 1500, 512, 2048, 1, False),
+                                             (16, 1500, 1024, 1024, 0, True), (6, 1500, 2048, 512, 0, True),
+                                             (64, 49, 256, 512, 2, False), (40, 499, 512, 768, 1, False)])
+def test_gemm_stream_shapes(B, T, K, N, act, res):
+    """more tiles than CUs (each workgroup walks several tiles on one operand stream), both block heights, clips shorter
+    than a tile (T = 49) and a residual epilogue; every frame and the halos are checked."""
+    a = G.Rows(B, T, K).set(_rand(B, T, K, seed=61))
+    x0 = _rand(B, T, N, seed=62)
+    x = G.Rows(B, T, N).set(x0)
+    w, bias = _rand(N, K, scale=K ** -0.5, seed=63), _rand(N, scale=0.1, seed=64)
+    wp, bp = G.pad_weight(w, bias)
+    assert B * a.P >= 2048 and wp.shape[0] == N
+    G.gemm(a.buf, a.lead * K, K, wp, B * a.P, N, a.P, T, x.buf, N, x.lead, x.P, bias=bp, res=x.buf if res else None,
+           ldres=N, alpha=0.5, act=act)
+    torch.cuda.synchronize()
+    y = a.get() @ _bf(w).T + bias
+    y = [y, F.gelu(y), F.relu(y)][act]
+    _close(x.get(), _bf(x0) + 0.5 * y if res else y, what="gemm_stream")
+    assert x.halo_is_zero()
+
+
+def test_gemm_stream_ragged_columns_and_conv_taps():
+    """n_valid < N (columns beyond it must stay untouched) and a 3-tap dilated conv through the streaming kernel."""
+    B, T, C, N, nv = 4, 1500, 256, 512, 328
+    x0 = _rand(B, T, C, seed=65)
+    a = G.Rows(B, T, C).set(x0)
+    w, bias = _rand(nv, C, 3, scale=(3 * C) ** -0.5, seed=66), _rand(nv, scale=0.1, seed=67)
+    wp, bp = G.pad_weight(w.permute(0, 2, 1).reshape(nv, 3 * C), bias)
+    wp = torch.cat([wp, torch.zeros(N - wp.shape[0], wp.shape[1], dtype=wp.dtype, device="cuda")])
+    bp = torch.cat([bp, torch.zeros(N - bp.shape[0], device="cuda")])
+    out = G.Rows(B, T, N)
+    out.buf.fill_(7.0)
+    dil = 2
+    G.gemm(a.buf, (a.lead - dil) * C, C, wp, B * a.P, nv, a.P, T, out.buf, N, out.lead, out.P, bias=bp, act=2, cin=C, tap_stride=dil * C)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv1d(_bf(x0).transpose(1, 2), _bf(w), bias, padding=dil, dilation=dil)).transpose(1, 2)
+    got = out.buf[out.lead:out.lead + B * out.P].view(B, out.P, N)
+    _close(got[:, :T, :nv].float(), ref, what="stream dilated conv")
+    assert bool((got[:, :T, nv:] == 7.0).all()) and bool((got[:, T:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,T,K,N,act", [(16, 1500, 512, 1536, 0), (16, 1500, 512, 2048, 1), (3, 1500, 768, 768, 0)])
+def test_gemm_stream_layernorm_fold(B, T, K, N, act):
+    """LN(x) W^T + b computed as rstd (x W'^T - mean s) + b' with the statistics taken inside the GEMM."""
+    x0 = _rand(B, T, K, seed=71) * 2.0 + 0.5
+    x0[..., 3] += 9.0                                  # an outlier channel, as real encoder states have
+    a = G.Rows(B, T, K).set(x0)
+    gamma, beta = 1.0 + 0.2 * _rand(K, seed=72), 0.1 * _rand(K, seed=73)
+    w, bias = _rand(N, K, scale=K ** -0.5, seed=74), _rand(N, scale=0.1, seed=75)
+    wf = (w * gamma).to(torch.bfloat16)
+    ln_s = wf.float().sum(1)
+    bf = bias + w @ beta
+    wp, bp = G.pad_weight(wf.float(), bf)
+    out = G.Rows(B, T, N)
+    G.gemm_ln(a.buf, a.lead * K, K, wp, B * a.P, N, a.P, T, out.buf, N, out.lead, out.P, bp, ln_s.contiguous(), 1e-5, act)
+    torch.cuda.synchronize()
+    y = F.layer_norm(a.get(), (K,), gamma, beta, 1e-5) @ w.T + bias
+    y = [y, F.gelu(y)][act]
+    _close(out.get(), y, rtol=2e-2, atol=2e-2, what="LN-folded gemm")
+    assert out.halo_is_zero()

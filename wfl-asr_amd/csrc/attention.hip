@@ -72,26 +72,45 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *(const bf16x8*)(qp + ks * 32);
   }
 
-  f32x4 o[QT][DT];
-  float mrun[QT], lrun[QT];
+  // Online softmax with a DEFERRED reference: scores are produced as s - mref (the S^T accumulators start at -mref, so
+  // the subtraction rides on the MFMA's C operand), P = exp2(s - mref), and mref moves only when a tile holds a score
+  // more than RESCALE_THR above it (tile 0 always sets it) -- then, and only then, O and the row sums are rescaled.
+  // Softmax is shift invariant, so any mref is exact as long as exp2 stays in range: P <= 2^THR by construction, and
+  // every row keeps the term exp2(0) = 1 of the key that set its mref, so the row sum cannot underflow.
+  // Row sums come from the matrix pipe: one extra V^T "channel" that is all ones (a constant A fragment, lane c == 0),
+  // accumulated like an output tile (osum[qt][0] of lanes g == 0), over the same bf16-rounded P as the numerator.
+  constexpr float RESCALE_THR = 8.0f;
+  f32x4 o[QT][DT], osum[QT], negm[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    mrun[qt] = -INFINITY;
-    lrun[qt] = 0.f;
+    negm[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    osum[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = f2bf(c == 0 ? 1.0f : 0.0f);
 
   const int ntiles = (p.T + KT - 1) / KT;
   bf16x8 kreg[KCH], vreg[KCH];
 
+  // per-lane element offsets inside a tile are fixed; the tile base is block-uniform (scalar base + 32-bit lane offset)
+  int koff[KCH], voff[KCH];
+#pragma unroll
+  for (int i = 0; i < KCH; ++i) {
+    const int ch = tid + 256 * i;
+    const int r = ch / CPR, cc = ch % CPR;
+    koff[i] = r * (int)p.ldqk + cc * 8;
+    voff[i] = r * (int)p.ldv + cc * 8;
+  }
   auto load_tile = [&](int kt) {
+    const bf16_t* kb = Kg + (row0 + (long)kt * KT) * p.ldqk;
+    const bf16_t* vb = Vg + (row0 + (long)kt * KT) * p.ldv;
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
-      const int ch = tid + 256 * i;
-      const int r = ch / CPR, cc = ch % CPR;
-      kreg[i] = *(const bf16x8*)(Kg + (row0 + kt * KT + r) * p.ldqk + cc * 8);
-      vreg[i] = *(const bf16x8*)(Vg + (row0 + kt * KT + r) * p.ldv + cc * 8);
+      kreg[i] = *(const bf16x8*)(kb + koff[i]);
+      vreg[i] = *(const bf16x8*)(vb + voff[i]);
     }
   };
   auto store_tile = [&]() {
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) st[qt][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < 4; ++kk) st[qt][kk] = negm[qt];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -159,41 +178,54 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           }
     }
 
-    // ---- online softmax (per query frame = per lane column c; the 4 lane groups g share a frame)
+    // ---- softmax numerators (per query frame = per lane column c; the 4 lane groups g share a frame)
     bf16x8 pf[QT][2];
+    {
+      float mx[QT];
+      bool over = kt == 0;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float m = st[qt][0][0];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m = fmaxf(m, st[qt][kk][e]);
+        mx[qt] = m;
+        over = over || m > RESCALE_THR;
+      }
+      if (__builtin_amdgcn_ballot_w64(over) != 0) {      // wave-uniform and rare after the first tiles
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          float m = mx[qt];
+          m = fmaxf(m, __shfl_xor(m, 16));
+          m = fmaxf(m, __shfl_xor(m, 32));
+          // raise-only (tile 0: take the tile's max, whatever its sign); a fully masked tile cannot occur (kt*KT < T)
+          const float d = kt == 0 ? m : fmaxf(m, 0.f);    // new mref - old mref
+          const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);   // (O and the sums are still zero at tile 0)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[qt][kk][e] -= d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) negm[qt][e] -= d;
+          osum[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+        }
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float mx = st[qt][0][0];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[qt][kk][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-      mrun[qt] = mnew;
-      float ps = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(st[qt][kk][e] - mnew);
-          st[qt][kk][e] = pv;
-          ps += pv;
-        }
-      lrun[qt] = lrun[qt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          t[e] = f2bf(st[qt][2 * s2][e]);
-          t[4 + e] = f2bf(st[qt][2 * s2 + 1][e]);
+          t[e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2][e]));
+          t[4 + e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2 + 1][e]));
         }
         pf[qt][s2] = t;
+        osum[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, t, osum[qt], 0, 0, 0);
       }
     }
 
@@ -218,9 +250,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   // ---- normalise and store: lane holds channels h*HD + 16dt + 4g + e of query frame q0 + 16qt + c
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l = lrun[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = __shfl(osum[qt][0], c);          // row sum of query c lives in lane (g = 0, c), register 0
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + c;
     if (q < p.T) {

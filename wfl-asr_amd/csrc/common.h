@@ -53,6 +53,9 @@ struct GemmArgs {
   int out_f32;
   bf16_t* Vt;               // columns >= vt_n0 are written transposed: Vt[(b * (n_valid - vt_n0) + n - vt_n0) * P + t]
   int vt_n0;                // (multiple of 128); frames t in [T, P) of Vt are written as zero
+  const float* ln_s;        // LayerNorm folded in front of the GEMM (gemm_stream.hip): s[n] = sum_k W'[n][k], W' = gamma o W,
+  float ln_eps;             //   bias = b + W beta;  out = rstd_m * (acc - mean_m * s[n]) + bias[n];  statistics over the K columns
+  void* trash;              // set by the launcher: >= 1 KiB scratch line for stores that must not land (gemm_stream.hip)
 #ifdef WFL_GEMM_STAMPS
   unsigned long long* stamps;   // diagnostic build: [blocks][8]
 #endif

@@ -365,6 +365,7 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
 }
 
 int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s);   // gemm256.hip; returns 1 when it does not take the shape
+int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s);   // gemm_stream.hip; likewise
 
 static int tile_pref() {
   static int pref = -1;
@@ -380,9 +381,13 @@ int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
       (!a.out_f32 && a.ldc % 8) || (a.res && a.ldres % 8) || (a.pos && a.ldpos % 8) || (a.Vt && a.vt_n0 % BN))
     return -1;
   if (tile_pref() == 256) {
-    const int r = wfl_launch_gemm256(a, s);
+    int r = wfl_launch_gemm_stream(a, s);
+    if (r != 1) return r;
+    if (a.ln_s) return -1;                          // only the streaming kernel folds a LayerNorm
+    r = wfl_launch_gemm256(a, s);
     if (r != 1) return r;
   }
+  if (a.ln_s) return -1;
   if (a.glu) {
     if (a.out_f32 || a.act != WFL_ACT_NONE || a.Vt) return -1;
     return launch_t<WFL_ACT_NONE, true, false, false>(a, s);

@@ -1,0 +1,428 @@
+// Persistent ("streaming") 256 x 256 x 32 bf16 MFMA GEMM for gfx950 -- the main kernel behind the Linear / Conv1d layers of
+// the WFL-ASR forward whose output is bf16 with a plain epilogue (bias, GELU/ReLU, residual, optionally a LayerNorm
+// folded in front).  Same GemmArgs contract as gemm.hip / gemm256.hip, which keep the GLU, fp32-output, positional-table
+// and per-clip-bias launches.  Replaces /root/reference/model.py:18-19, 26, 31-37, 131, 140 and HF
+// modeling_whisper.py:309-354, 391-407 (q/k/v/out projections, FFN), HF modeling_whisper.py:384-385/401-402 (the
+// pre-LayerNorms, when folded).
+//
+// What differs from gemm256.hip (whose tile, ring, swizzle and ping-pong K loop it shares):
+//   * one workgroup per CU walks tiles v = blockIdx.x, + gridDim.x, ... and keeps ONE operand stream going across tile
+//     boundaries: the LDS-DMA for the first three K steps of the next tile is issued during the last three steps of
+//     the current one, so a tile never pays the ~2 us pipeline fill again;
+//   * the epilogue never touches LDS (the ring belongs to the next tile by then): the weight-tile rows each lane feeds
+//     to the MFMA are permuted so that a lane ends up with two runs of 8 consecutive output channels of one frame, i.e.
+//     two 16-byte stores per 16-frame tile, 64 contiguous bytes per frame per store instruction.  The stores are not
+//     waited for: they drain under the next tile's K loop (vmcnt counts them, in order, so the first two waits of a new
+//     tile allow for them; from the third on they must have retired).  Stores of rows / columns that must not be written
+//     (halo frames, n >= n_valid) go to a scratch line instead of being branched around, which keeps the count exact;
+//   * each wave group runs the previous tile's epilogue at the start of its first L slot of the next tile, i.e. while the
+//     other group owns the matrix pipe;
+//   * LayerNorm folding (GemmArgs::ln_s != null):  LN(x) W^T + b = rstd * (x W'^T - mean * s) + b'  with W' = gamma o W,
+//     s_n = sum_k W'_nk, b' = b + W beta (packed at load time).  The row statistics come from the very fragments the
+//     MFMAs consume: in every C slot each wave adds up its share of the frame fragments with v_dot2c_f32_bf16 (sum and
+//     sum of squares, fp32), the four waves of a group exchange the 16-frame partials through 1 KiB of LDS at the end
+//     of the tile, and the epilogue applies the affine correction -- the LayerNorm costs no launch and no HBM pass.
+#include "common.h"
+#include <cstdlib>
+#include <type_traits>
+
+#define SBK 32
+#define SNST 4
+#define SNCU 256
+
+typedef __attribute__((address_space(1))) const void* sgptr_t;
+typedef __attribute__((address_space(3))) void* slptr_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+static __device__ __forceinline__ void sglds(const bf16_t* g, char* l) {
+  __builtin_amdgcn_global_load_lds((sgptr_t)g, (slptr_t)l, 16, 0, 0);
+}
+static __device__ __forceinline__ int sswz(int row) { return (-(row >> 2)) & 3; }
+template <int N>
+static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#ifdef WFL_GEMM_STAMPS
+#define SSTAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SSTAMP(k) do { } while (0)
+#endif
+
+template <int ACT, int MT, bool RES, bool LNF>
+__global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
+  constexpr int BMV = MT * 32;                    // frame rows per tile
+#ifdef WFL_LAB_STB32
+  constexpr int STB = 512 * SBK * 2;
+  constexpr int WOFF = 256 * SBK * 2;
+#else
+  constexpr int STB = (BMV + 256) * SBK * 2;      // stage bytes: frame tile then weight tile
+  constexpr int WOFF = BMV * SBK * 2;
+#endif
+  constexpr int NSTORE = 2 * MT;                  // epilogue stores per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stat_lds = (float*)(smem + SNST * STB);  // [2 groups][MT*16 rows][2]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wq = wid & 3;
+  const int g = lane >> 4, c = lane & 15;
+  const int G = gridDim.x;
+
+  SSTAMP(0);
+  const int tiles_n = p.N / 256;
+  const int tiles_m = (p.M + BMV - 1) / BMV;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = p.K / SBK;
+  auto tile_of = [&](int v, int& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware order: v and v + 8 share an XCD; contiguous run per XCD
+    const int q = ntiles >> 3, r = ntiles & 7, x = v & 7, i = v >> 3;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    const int tm = bid / tiles_n;
+    m0 = tm * BMV;
+    n0 = (bid - tm * tiles_n) * 256;
+  };
+  const int wm = grp * (MT * 16), wn = wq * 64;
+
+  // ---- operand stream (prefetch cursor).  Frame row groups: MT = 8: waves load two each; MT = 6: waves 0-3 two, 4-7 one.
+  const bool two_x = MT == 8 || wid < 4;
+  const int xg0 = (MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4);
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+  int pv = blockIdx.x, pkt = 0, issued = 0;
+  int ptap_k = 0;                                   // position inside the current tap (conv GEMMs), elements
+  long pbase = 0;                                   // tap * tap_stride
+  auto set_src = [&](int v) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_of(v, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int wrow = (wid * 2 + i) * 16 + (lane >> 2);
+      const int xrow = (xg0 + i) * 16 + (lane >> 2);
+      int am = m0 + xrow;
+      am = am < p.M ? am : p.M - 1;
+      a_src[i] = p.A + (long)am * p.lda + ((lane & 3) ^ sswz(xrow)) * 8;
+      w_src[i] = p.W + (long)(n0 + wrow) * p.K + ((lane & 3) ^ sswz(wrow)) * 8;
+    }
+  };
+  set_src(pv);
+  auto issue_stage = [&]() __attribute__((always_inline)) {                        // the DMA of stage (pv, pkt); advances the position inside the tile
+    const long koff = pbase + ptap_k;
+    char* base = smem + (issued & (SNST - 1)) * STB;
+    sglds(a_src[0] + koff, base + xg0 * 1024);
+    if (two_x) sglds(a_src[1] + koff, base + xg0 * 1024 + 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) sglds(w_src[i] + pkt * SBK, base + WOFF + wid * 2048 + i * 1024);
+    ++issued;
+    ++pkt;
+    ptap_k += SBK;
+    if (ptap_k == p.cin) { ptap_k = 0; pbase += p.tap_stride; }
+  };
+  auto prefetch_one = [&]() __attribute__((always_inline)) {                       // issue the next stage of the stream, if there is one
+    if (pv >= ntiles) return;
+    issue_stage();
+    if (pkt == nk) {
+      pkt = 0; ptap_k = 0; pbase = 0;
+      pv += G;
+      if (pv < ntiles) set_src(pv);
+    }
+  };
+  // wait until the stage of global step `need` has landed (this wave's part), given `issued` stages so far and whether an
+  // epilogue's stores were issued after it.  Younger stages: issued - need - 1 in {0, 1, 2}.
+  auto wait_stage = [&](int need, bool with_stores) __attribute__((always_inline)) {
+    const int younger = issued - need - 1;
+    if (younger < 0) return;                        // no such stage (end of the stream)
+    if (two_x) {
+      if (younger >= 2) { if (with_stores) wait_vm<8 + NSTORE>(); else wait_vm<8>(); }
+      else if (younger == 1) { if (with_stores) wait_vm<4 + NSTORE>(); else wait_vm<4>(); }
+      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
+    } else {
+      if (younger >= 2) { if (with_stores) wait_vm<6 + NSTORE>(); else wait_vm<6>(); }
+      else if (younger == 1) { if (with_stores) wait_vm<3 + NSTORE>(); else wait_vm<3>(); }
+      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
+    }
+  };
+
+  // ---- fragment addressing.  Weight-tile row feeding MFMA row i of column tile v is channel
+  //   ch(v, i) = 32 (v >> 1) + 8 (i >> 2) + 4 (v & 1) + (i & 3)
+  // so that lane (g, c) holds channels 8g .. 8g+7 (v = 0, 1) and 32 + 8g .. +7 (v = 2, 3) of frame c.
+  int w_off[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+#ifdef WFL_LAB_NOPERM
+    const int r = wn + 16 * v + c;
+#else
+    const int r = wn + 32 * (v >> 1) + 8 * (c >> 2) + 4 * (v & 1) + (c & 3);
+#endif
+    w_off[v] = WOFF + r * 64 + ((g ^ sswz(r)) << 4);
+  }
+  const int x_off = wm * 64 + c * 64 + ((g ^ sswz(c)) << 4);      // + u * 1024 (16 rows; sswz(16u + c) == sswz(c))
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int u = 0; u < MT; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // LayerNorm statistics partials of this wave's share of the 16-frame tiles: u in [u_lo, u_hi)
+  const int u_lo = (MT * wq) / 4, u_hi = (MT * (wq + 1)) / 4;
+  float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;   // (named, not an array: a runtime index would send them to scratch)
+
+  // ---- epilogue of tile (m0, n0): registers -> HBM
+  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int nb = n0 + wn + 8 * g;                 // first channel of this lane's first run; second run at +32
+    f32x4 bj[4], sj[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bj[2 * h + q] = p.bias ? *(const f32x4*)(p.bias + nb + 32 * h + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (LNF) sj[2 * h + q] = *(const f32x4*)(p.ln_s + nb + 32 * h + 4 * q);
+      }
+    const float invP = 1.0f / (float)p.P;
+    int orow[MT];                                   // output row index, or -1 for rows that are not stored
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int m = m0 + wm + 16 * u + c;
+      int b = (int)((float)m * invP);
+      int t = m - b * p.P;
+      if (t < 0) { t += p.P; --b; }
+      if (t >= p.P) { t -= p.P; ++b; }
+      orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * p.c_pitch + t : -1;
+    }
+    bf16x8 rr[RES ? MT : 1][2];
+    if (RES) {
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        const long r = orow[u] >= 0 ? orow[u] : p.c_lead;   // any valid row: the value is never stored
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rr[u][h] = *(const bf16x8*)(p.res + r * p.ldres + nb + 32 * h);
+      }
+    }
+    float mu[LNF ? MT : 1], rs[LNF ? MT : 1];
+    if (LNF) {
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        const float2 s = *(const float2*)(stat_lds + (grp * (MT * 16) + u * 16 + c) * 2);
+        mu[u] = s.x;
+        rs[u] = s.y;
+      }
+    }
+    char* trash = (char*)p.trash + lane * 16;
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      __builtin_amdgcn_sched_barrier(0);            // one 16-frame tile at a time: keeps the register footprint bounded
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[u][2 * h + q][e];
+            if (LNF) v = (v - mu[u] * sj[2 * h + q][e]) * rs[u];
+            v = apply_act<ACT>(v + bj[2 * h + q][e]);
+            if (RES) v = bf2f(rr[u][h][4 * q + e]) + p.alpha * v;
+            x[4 * q + e] = v;
+          }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(x[e]);
+        char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
+        dst = (orow[u] >= 0 && nb + 32 * h < p.n_valid) ? dst : trash;
+        *(bf16x8*)dst = o;
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  // ---- prologue: three stages in flight, stage 0 landed, group 1 one barrier behind
+#pragma unroll
+  for (int t = 0; t < SNST - 1; ++t) prefetch_one();
+  wait_stage(0, false);
+  __builtin_amdgcn_s_barrier();
+  SSTAMP(1);
+  if (grp) __builtin_amdgcn_s_barrier();
+
+#define SSB() __builtin_amdgcn_sched_barrier(0)
+  bf16x8 fw[4], fx[MT];
+  int s = 0;                                         // global K-step counter (ring slot = s & 3)
+  auto read_frags = [&]() __attribute__((always_inline)) {
+    const char* sb = smem + (s & (SNST - 1)) * STB;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fw[v] = *(const bf16x8*)(sb + w_off[v]);
+#pragma unroll
+    for (int u = 0; u < MT; ++u) fx[u] = *(const bf16x8*)(sb + x_off + u * 1024);
+  };
+  auto mma_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
+  };
+  auto ln_accumulate = [&]() __attribute__((always_inline)) {
+    const bf16x2 one2 = {(bf16_t)1.0f, (bf16_t)1.0f};
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      if (u == u_lo) {                               // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x2 xv = {fx[u][2 * j], fx[u][2 * j + 1]};
+          sa1 = __builtin_amdgcn_fdot2_f32_bf16(xv, one2, sa1, false);
+          sa2 = __builtin_amdgcn_fdot2_f32_bf16(xv, xv, sa2, false);
+        }
+      }
+      if (u == u_lo + 1 && u < u_hi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x2 xv = {fx[u][2 * j], fx[u][2 * j + 1]};
+          sb1 = __builtin_amdgcn_fdot2_f32_bf16(xv, one2, sb1, false);
+          sb2 = __builtin_amdgcn_fdot2_f32_bf16(xv, xv, sb2, false);
+        }
+      }
+    }
+  };
+  auto ln_publish = [&]() __attribute__((always_inline)) {                          // mean / rstd of this wave's frames -> its group's LDS table
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float a1 = i ? sb1 : sa1, a2 = i ? sb2 : sa2;
+      a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+      a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+      const float mean = a1 / (float)p.K;
+      const float var = fmaxf(a2 / (float)p.K - mean * mean, 0.f);
+      if (u_lo + i < u_hi && g == 0) {
+        float2 o = {mean, rsqrtf(var + p.ln_eps)};
+        *(float2*)(stat_lds + (grp * (MT * 16) + (u_lo + i) * 16 + c) * 2) = o;
+      }
+    }
+    sa1 = sa2 = sb1 = sb2 = 0.f;
+  };
+  int pm0 = 0, pn0 = 0;
+  bool have_prev = false;
+  for (int tv = blockIdx.x; tv < ntiles; tv += G) {
+    int m0, n0;
+    tile_of(tv, m0, n0);
+    const bool last_tile = tv + G >= ntiles;
+    // One K step, general form: used for the first two steps of a tile (the previous tile's epilogue and its stores sit in
+    // the vmcnt queue) and the last four (the stream crosses into the next tile, or ends).
+    auto step_general = [&](int kt, auto first_c) __attribute__((always_inline)) {
+      if (decltype(first_c)::value && have_prev) epilogue(pm0, pn0);
+      read_frags();
+      prefetch_one();
+      if (grp) wait_stage(s + 1, have_prev && kt < 2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      SSB();
+      mma_all();
+      if (LNF) {
+        ln_accumulate();
+        if (kt == nk - 1) ln_publish();
+      }
+      SSB();
+      if (!grp) wait_stage(s + 1, have_prev && kt < 2);
+      if (LNF) __builtin_amdgcn_s_waitcnt(0xC07F);   // the statistics are in LDS before the barrier
+      if (LNF || !(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
+      SSB();
+      ++s;
+    };
+    // Steady state, kt in [2, nk - 5]: the stage being issued (kt + 3) and the two awaited next lie inside this tile and
+    // nothing but operand DMA is in the queue, so the waits are constants.  One copy per wave group (no per-step branches).
+    auto steps_steady = [&](auto grp_c) __attribute__((always_inline)) {
+      constexpr bool GRP1 = decltype(grp_c)::value;
+      constexpr int NL = (MT == 8 || !GRP1) ? 4 : 3;
+      for (int kt = 2; kt <= nk - 5; ++kt) {
+        read_frags();
+        issue_stage();
+        if (GRP1) wait_vm<2 * NL>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        SSB();
+        mma_all();
+        if (LNF) ln_accumulate();
+        SSB();
+        if (!GRP1) wait_vm<2 * NL>();
+        __builtin_amdgcn_s_barrier();
+        SSB();
+        ++s;
+      }
+    };
+    step_general(0, std::true_type{});
+    step_general(1, std::false_type{});
+    if (grp) steps_steady(std::true_type{}); else steps_steady(std::false_type{});
+    for (int kt = nk - 4 > 2 ? nk - 4 : 2; kt < nk; ++kt) step_general(kt, std::false_type{});
+    pm0 = m0; pn0 = n0;
+    have_prev = true;
+  }
+  SSTAMP(2);
+  SSTAMP(3);
+  if (have_prev) epilogue(pm0, pn0);
+  if (LNF && !grp) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+  SSTAMP(4);
+#undef SSB
+}
+
+template <int ACT, int MT, bool RES, bool LNF>
+static int launch_stream(const GemmArgs& a, hipStream_t s) {
+  constexpr int BMV = MT * 32;
+#ifdef WFL_LAB_STB32
+  constexpr int lds = SNST * 512 * SBK * 2 + 2 * (MT * 16) * 2 * 4;
+#else
+  constexpr int lds = SNST * (BMV + 256) * SBK * 2 + 2 * (MT * 16) * 2 * 4;
+#endif
+  const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
+  auto k = gemm_stream_kernel<ACT, MT, RES, LNF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Block height.  192 rows everywhere: with tiles dealt round-robin to persistent workgroups the 256-row block only wins when
+// it saves a whole round, and hipcc (ROCm 7.2) cannot hold its 128 accumulators + 48 fragment registers + the epilogue
+// state in 256 VGPRs without spilling into the K loop (measured: fc1 124 us with the spilling 256-row build, 74 us with
+// 192 rows).  WFL_GEMM_BM=256 still selects it for experiments.
+template <int ACT, bool RES, bool LNF>
+static int launch_stream_mt(const GemmArgs& a, hipStream_t s) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0; }
+#ifdef WFL_STREAM_MT8
+  if (forced == 256) return launch_stream<ACT, 8, RES, LNF>(a, s);
+#endif
+  return launch_stream<ACT, 6, RES, LNF>(a, s);
+}
+
+// Returns 1 when this kernel does not take the launch (caller falls back to gemm256 / gemm).
+int wfl_launch_gemm_stream(const GemmArgs& a_in, hipStream_t s) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("WFL_GEMM_NO_STREAM"); off = e && atoi(e) ? 1 : 0; }
+  if (off) return 1;
+#ifdef WFL_LAB_NOSTREAM
+  return 1;
+#endif
+  const GemmArgs& a = a_in;
+  if (a.glu || a.out_f32 || a.pos || a.clip_bias) return 1;
+  if (a.N % 256 || a.K % SBK || a.cin % SBK || a.M < 2048 || a.K / SBK < 4 || a.n_valid % 8) return 1;
+  if (a.res && a.act != WFL_ACT_NONE) return 1;
+  if (a.ln_s && (a.res || a.cin < a.K)) return 1;
+  if (a.act == WFL_ACT_SIGMOID) return 1;
+  static void* trash = nullptr;
+  if (!trash) {
+    if (hipMalloc(&trash, 4096) != hipSuccess) return -2;
+  }
+  GemmArgs g = a;
+  g.trash = trash;
+  if (g.ln_s) {
+    switch (g.act) {
+      case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, true>(g, s);
+      case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, true>(g, s);
+    }
+    return 1;
+  }
+  if (g.res) return launch_stream_mt<WFL_ACT_NONE, true, false>(g, s);
+  switch (g.act) {
+    case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, false>(g, s);
+    case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, false>(g, s);
+    case WFL_ACT_RELU: return launch_stream_mt<WFL_ACT_RELU, false, false>(g, s);
+  }
+  return 1;
+}

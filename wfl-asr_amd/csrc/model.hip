@@ -1176,6 +1176,19 @@ int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride,
   return r ? fail(r, "wfl_op_gemm: invalid arguments or launch failure (" + std::to_string(r) + ")") : 0;
 }
 
+int32_t wfl_op_gemm_ln(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, int32_t n_valid, int32_t P,
+                       int32_t T, void* C, int64_t ldc, int64_t c_lead, int32_t c_pitch, const float* bias, const float* ln_s,
+                       float ln_eps, int32_t act, void* stream) {
+  if (!ln_s) return fail(-1, "wfl_op_gemm_ln: ln_s is required");
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.lda = lda; g.cin = K; g.tap_stride = 0;
+  g.W = (const bf16_t*)W; g.M = M; g.N = N; g.K = K; g.n_valid = n_valid; g.P = P; g.T = T;
+  g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch; g.bias = bias; g.alpha = 1.f; g.act = act;
+  g.ln_s = ln_s; g.ln_eps = ln_eps;
+  const int r = wfl_launch_gemm(g, (hipStream_t)stream);
+  return r ? fail(r, "wfl_op_gemm_ln: shape not supported by the LayerNorm-folding kernel or launch failure (" + std::to_string(r) + ")") : 0;
+}
+
 int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* V, int64_t ldv, void* O, int64_t ldo, int32_t B, int32_t T,
                          int32_t P, int32_t heads, int32_t d, void* stream) {
   AttnArgs a{};
