@@ -205,25 +205,39 @@ def main():
         audio_s = world * B * CLIP_SECONDS * args.steps
         roof = None
         if prof:
-            names = {0: "none", 1: "gelu", 2: "relu", 3: "sigmoid"}
+            acts = {0: 0, 1: 1, 2: 2, 3: 3}
+
+            def kname(key):
+                """rocprofv3 kernel name of the template instantiation behind a profile key (model.hip: Runner::gemm)."""
+                act, glu, f32, res, kid = key & 3, bool(key & 4), bool(key & 8), bool(key & 16), key >> 5
+                tf = lambda b: "true" if b else "false"
+                if kid in (1, 5):
+                    return "gemm_stream_kernel<%d, %d, %s, false>" % (acts[act], 6 if kid == 1 else 8, tf(res))
+                if kid in (2, 3):
+                    return "gemm256_kernel<%d, %s, %s, %d, false>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
+                return "gemm_bf16_kernel<%d, %s, %s, false>" % (acts[act], tf(glu), tf(f32))
+
             tot_ms = sum(p["ms"] for p in prof)
             tot_fl = sum(p["flops"] for p in prof)
             tot_n = sum(p["launches"] for p in prof)
             top = max(prof, key=lambda p: p["ms"])
+            traffic = pmc_traffic()
             roof = {
-                "bound": "mfma", "kernel": "gemm_bf16_kernel<ACT,GLU,OUTF32,VT> (all instantiations)",
-                "timing": "HIP events around every GEMM launch, same %d steps re-run eagerly after the timed region "
-                          "(%.3f ms/step with events)" % (args.steps, eager_ms),
+                "bound": "mfma",
+                "kernel": "bf16 MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations)",
+                "timing": "HIP events (launch stream) around every GEMM launch of a second pass over the same %d steps, run "
+                          "right after the timed region (%.3f ms/step with the events in)" % (args.steps, eager_ms),
                 "achieved": tot_fl / tot_ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
                 "launches_per_step": tot_n / args.steps, "avg_launch_us": 1e3 * tot_ms / tot_n,
                 "gflop_per_launch": tot_fl / tot_n / 1e9, "gemm_ms_per_step": tot_ms / args.steps,
                 "variants": [
-                    {"act": names[p["key"] & 7], "glu": bool(p["key"] & 8), "out_f32": bool(p["key"] & 16),
-                     "vt": bool(p["key"] & 32), "launches": p["launches"], "avg_us": 1e3 * p["ms"] / p["launches"],
-                     "tflops": p["flops"] / p["ms"] / 1e9}
+                    {"kernel": kname(p["key"]), "launches": p["launches"], "avg_us": 1e3 * p["ms"] / p["launches"],
+                     "tflops": p["flops"] / p["ms"] / 1e9, "frac": p["flops"] / p["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS}
                     for p in sorted(prof, key=lambda p: -p["ms"])],
-                "top_variant": {"act": names[top["key"] & 7], "avg_us": 1e3 * top["ms"] / top["launches"],
+                "top_variant": {"kernel": kname(top["key"]), "avg_us": 1e3 * top["ms"] / top["launches"],
                                 "tflops": top["flops"] / top["ms"] / 1e9},
             }
         result = {

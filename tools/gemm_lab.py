@@ -18,11 +18,11 @@ DRV = '''
 #include "common.h"
 extern "C" int diag_gemm(const void* A, long lda, int cin, long tap_stride, const void* W, int M, int N, int K, int P, int T,
                          void* Cout, long ldc, long c_lead, const float* bias, const void* res, int act, unsigned long long* stamps,
-                         void* stream) {
+                         const float* ln_s, void* stream) {
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.cin = cin > 0 ? cin : K; g.tap_stride = tap_stride; g.W = (const bf16_t*)W;
   g.M = M; g.N = N; g.K = K; g.n_valid = N; g.P = P; g.T = T; g.C = Cout; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = P;
-  g.bias = bias; g.res = (const bf16_t*)res; g.ldres = ldc; g.alpha = 1.f; g.act = act; g.stamps = stamps;
+  g.bias = bias; g.res = (const bf16_t*)res; g.ldres = ldc; g.alpha = 1.f; g.act = act; g.stamps = stamps; g.ln_s = ln_s; g.ln_eps = 1e-5f;
   return wfl_launch_gemm(g, (hipStream_t)stream);
 }
 '''
@@ -41,6 +41,7 @@ def build(name, flags):
 
 
 SHAPES = [("out_proj+res", 512, 512, 0, True), ("qkv-like", 512, 1536, 0, False), ("fc1 gelu", 512, 2048, 1, False),
+          ("qkvLN", 512, 1536, 0, False), ("fc1LN gelu", 512, 2048, 1, False),
           ("fc2+res", 2048, 512, 0, True), ("k31 conv gelu", 15872, 512, 1, False), ("ff1_b", 1024, 512, 0, True)]
 
 
@@ -60,7 +61,7 @@ def main():
             path = build(name, fl)
         lib = C.CDLL(path)
         lib.diag_gemm.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                  C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                                  C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         libs[name] = lib
     B, T, P, lead = 16, 1500, 1520, 16
     M = B * P
@@ -80,18 +81,23 @@ def main():
         lda = kin if K <= 2048 else 512
         aoff = lead * lda * 2
         fl = 2.0 * B * T * N * K
+        ln = "LN" in name
+        ln_s = W.float().sum(1).contiguous()
 
         def run(lib, with_stamps):
             return lib.diag_gemm(C.c_void_p(A.data_ptr() + aoff), lda, 0, 0, C.c_void_p(W.data_ptr()), M, N, K, P, T,
                                  C.c_void_p(Cb.data_ptr()), N, lead, C.c_void_p(bias.data_ptr()),
                                  C.c_void_p(Rs.data_ptr()) if res else None, act,
-                                 C.c_void_p(stamps.data_ptr()) if with_stamps else None, st)
+                                 C.c_void_p(stamps.data_ptr()) if with_stamps else None,
+                                 C.c_void_p(ln_s.data_ptr()) if ln else None, st)
 
         times = {n: [] for n in libs}
         # independent reference for 64 rows spread over the run (fp32 matmul of the bf16 operands)
         ridx = torch.arange(0, 64, device="cuda") * 379 % (B * P)
         ridx = ridx[(ridx % P) < T]
         Arows = torch.as_strided(A.view(-1), (B * P, K), (lda, 1), lead * lda)[ridx].float()
+        if ln:
+            Arows = torch.nn.functional.layer_norm(Arows, (K,))
         ref = Arows @ W.float().T + bias
         if act == 1:
             ref = torch.nn.functional.gelu(ref)

@@ -103,6 +103,9 @@ static __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
 // host-side launchers (one per .hip translation unit)
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s);
+// which kernel the last wfl_launch_gemm used (profiling labels): 1 gemm_stream<.,6>, 2 gemm256<.,6>, 3 gemm256<.,8>, 4 gemm_bf16 (128 tile), 5 gemm_stream<.,8>
+extern int g_wfl_gemm_kernel_id;
+bool wfl_gemm_stream_takes(const GemmArgs& a);   // gemm_stream.hip: would the streaming (LayerNorm-folding) kernel take it
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s);
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
                          long lead, int B, int P, int T, int C, hipStream_t s);

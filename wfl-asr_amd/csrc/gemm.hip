@@ -360,9 +360,12 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -2;
     attr_set = true;
   }
+  g_wfl_gemm_kernel_id = 4;
   hipLaunchKernelGGL(k, dim3(tiles), dim3(256), LDS_BYTES, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+int g_wfl_gemm_kernel_id = 0;
 
 int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s);   // gemm256.hip; returns 1 when it does not take the shape
 int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s);   // gemm_stream.hip; likewise

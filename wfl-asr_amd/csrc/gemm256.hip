@@ -369,6 +369,7 @@ static int launch256_mt(const GemmArgs& a, hipStream_t s) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return -2;
     attr_set = true;
   }
+  g_wfl_gemm_kernel_id = MT == 6 ? 2 : 3;
   hipLaunchKernelGGL(k, dim3(tiles), dim3(512), LDS2, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

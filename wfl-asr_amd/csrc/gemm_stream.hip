@@ -160,8 +160,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   for (int u = 0; u < MT; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // LayerNorm statistics partials of this wave's share of the 16-frame tiles: u in [u_lo, u_hi)
-  const int u_lo = (MT * wq) / 4, u_hi = (MT * (wq + 1)) / 4;
+  // LayerNorm statistics partials of this wave's share of the 16-frame tiles (u = wq and wq + 4)
   float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;   // (named, not an array: a runtime index would send them to scratch)
 
   // ---- epilogue of tile (m0, n0): registers -> HBM
@@ -251,35 +250,32 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int u = 0; u < MT; ++u) fx[u] = *(const bf16x8*)(sb + x_off + u * 1024);
   };
+  // The MFMAs of one K step; with a folded LayerNorm, wave wq of a group also sums the frame fragments u = wq and wq + 4
+  // (v_dot2c_f32_bf16: sum and sum of squares), issued right behind that tile's MFMAs so they run in the MFMAs' shadow.
   auto mma_all = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < MT; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
-  };
-  auto ln_accumulate = [&]() __attribute__((always_inline)) {
     const bf16x2 one2 = {(bf16_t)1.0f, (bf16_t)1.0f};
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
-      if (u == u_lo) {                               // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x2 xv = {fx[u][2 * j], fx[u][2 * j + 1]};
-          sa1 = __builtin_amdgcn_fdot2_f32_bf16(xv, one2, sa1, false);
-          sa2 = __builtin_amdgcn_fdot2_f32_bf16(xv, xv, sa2, false);
-        }
-      }
-      if (u == u_lo + 1 && u < u_hi) {
+      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
+      if (LNF) {
+        if ((u & 3) == wq) {                         // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x2 xv = {fx[u][2 * j], fx[u][2 * j + 1]};
-          sb1 = __builtin_amdgcn_fdot2_f32_bf16(xv, one2, sb1, false);
-          sb2 = __builtin_amdgcn_fdot2_f32_bf16(xv, xv, sb2, false);
+          for (int j = 0; j < 4; ++j) {
+            const bf16x2 xv = {fx[u][2 * j], fx[u][2 * j + 1]};
+            if (u < 4) {
+              sa1 = __builtin_amdgcn_fdot2_f32_bf16(xv, one2, sa1, false);
+              sa2 = __builtin_amdgcn_fdot2_f32_bf16(xv, xv, sa2, false);
+            } else {
+              sb1 = __builtin_amdgcn_fdot2_f32_bf16(xv, one2, sb1, false);
+              sb2 = __builtin_amdgcn_fdot2_f32_bf16(xv, xv, sb2, false);
+            }
+          }
         }
       }
     }
   };
-  auto ln_publish = [&]() __attribute__((always_inline)) {                          // mean / rstd of this wave's frames -> its group's LDS table
+  auto ln_publish = [&]() __attribute__((always_inline)) {   // mean / rstd of this wave's frames -> its group's LDS table
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float a1 = i ? sb1 : sa1, a2 = i ? sb2 : sa2;
@@ -287,9 +283,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
       const float mean = a1 / (float)p.K;
       const float var = fmaxf(a2 / (float)p.K - mean * mean, 0.f);
-      if (u_lo + i < u_hi && g == 0) {
+      const int u = wq + 4 * i;
+      if (u < MT && g == 0) {
         float2 o = {mean, rsqrtf(var + p.ln_eps)};
-        *(float2*)(stat_lds + (grp * (MT * 16) + (u_lo + i) * 16 + c) * 2) = o;
+        *(float2*)(stat_lds + (grp * (MT * 16) + u * 16 + c) * 2) = o;
       }
     }
     sa1 = sa2 = sb1 = sb2 = 0.f;
@@ -311,10 +308,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
       SSB();
       mma_all();
-      if (LNF) {
-        ln_accumulate();
-        if (kt == nk - 1) ln_publish();
-      }
+      if (LNF && kt == nk - 1) ln_publish();
       SSB();
       if (!grp) wait_stage(s + 1, have_prev && kt < 2);
       if (LNF) __builtin_amdgcn_s_waitcnt(0xC07F);   // the statistics are in LDS before the barrier
@@ -335,7 +329,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         __builtin_amdgcn_s_barrier();
         SSB();
         mma_all();
-        if (LNF) ln_accumulate();
         SSB();
         if (!GRP1) wait_vm<2 * NL>();
         __builtin_amdgcn_s_barrier();
@@ -373,6 +366,7 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
     attr_set = true;
   }
+  g_wfl_gemm_kernel_id = MT == 6 ? 1 : 5;
   hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -391,20 +385,28 @@ static int launch_stream_mt(const GemmArgs& a, hipStream_t s) {
   return launch_stream<ACT, 6, RES, LNF>(a, s);
 }
 
-// Returns 1 when this kernel does not take the launch (caller falls back to gemm256 / gemm).
-int wfl_launch_gemm_stream(const GemmArgs& a_in, hipStream_t s) {
+// The launches this kernel takes (everything else stays with gemm256 / gemm).
+bool wfl_gemm_stream_takes(const GemmArgs& a) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("WFL_GEMM_NO_STREAM"); off = e && atoi(e) ? 1 : 0; }
-  if (off) return 1;
+  if (off) return false;
 #ifdef WFL_LAB_NOSTREAM
-  return 1;
+  return false;
 #endif
-  const GemmArgs& a = a_in;
-  if (a.glu || a.out_f32 || a.pos || a.clip_bias) return 1;
-  if (a.N % 256 || a.K % SBK || a.cin % SBK || a.M < 2048 || a.K / SBK < 4 || a.n_valid % 8) return 1;
-  if (a.res && a.act != WFL_ACT_NONE) return 1;
-  if (a.ln_s && (a.res || a.cin < a.K)) return 1;
-  if (a.act == WFL_ACT_SIGMOID) return 1;
+  if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
+  if (a.N % 256 || a.K % SBK || a.cin % SBK || a.K / SBK < 8 || a.n_valid % 8) return false;
+  // a folded LayerNorm must not depend on the batch (a clip labelled alone has to equal the same clip inside a batch bit for
+  // bit); the plain launches are bit-identical across the three GEMM kernels, so small ones may go to the 128x128 tile
+  if (!a.ln_s && a.M < 2048) return false;
+  if (a.res && a.act != WFL_ACT_NONE) return false;
+  if (a.ln_s && (a.res || a.cin < a.K || (a.act != WFL_ACT_NONE && a.act != WFL_ACT_GELU))) return false;
+  if (a.act == WFL_ACT_SIGMOID) return false;
+  return true;
+}
+
+// Returns 1 when this kernel does not take the launch (caller falls back to gemm256 / gemm).
+int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {
+  if (!wfl_gemm_stream_takes(a)) return 1;
   static void* trash = nullptr;
   if (!trash) {
     if (hipMalloc(&trash, 4096) != hipSuccess) return -2;

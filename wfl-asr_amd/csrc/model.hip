@@ -121,20 +121,21 @@ struct Lin {
   bf16_t* W = nullptr;   // [N][K] padded
   float* bias = nullptr; // [N] padded (may be null)
   int N = 0, K = 0, n_valid = 0;
+  float* ln_s = nullptr; // set on a LayerNorm-folded operand: s[n] = sum_k W'[n][k] (gemm_stream.hip), bias = b + W beta
 };
 struct LNp { float* g = nullptr; float* b = nullptr; };
 
-struct EncLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2; };
+struct EncLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2, qkv_ln, fc1_ln; };   // *_ln: the LayerNorm in front folded in
 struct WavlmLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2; float *w8 = nullptr, *b8 = nullptr, *cst = nullptr; };
 struct ConfLayer {
   LNp ff1_ln, ff2_ln, ln1, ln2;
-  Lin ff1_a, ff1_b, ff2_a, ff2_b, qkv, out, pw1, conv, pw2;
+  Lin ff1_a, ff1_b, ff2_a, ff2_b, qkv, out, pw1, conv, pw2, ff1_a_ln, ff2_a_ln;
 };
 
-// GEMM launches are timed per kernel variant (template instantiation), keyed act | glu<<3 | out_f32<<4 | vt<<5
+// GEMM launches are timed per kernel variant (template instantiation), keyed act | glu<<2 | out_f32<<3 | res<<4 | kernel id<<5
 struct GemmProf {
-  long launches[64] = {0};
-  double flops[64] = {0};
+  long launches[256] = {0};
+  double flops[256] = {0};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<int> key;
 };
@@ -296,6 +297,44 @@ struct Packer {
     return L;
   }
 
+  // LayerNorm(gamma, beta) folded into the Linear that consumes it (gemm_stream.hip): W' = gamma o W rounded to bf16,
+  // s[n] = sum_k W'[n][k] over the ROUNDED weights (what the MFMA multiplies), bias' = bias + W beta.
+  Lin pack_ln(const std::vector<float>& rows, int n_valid, int k_valid, const std::vector<float>* bias, const std::string& ln_name) {
+    const HostTensor* g = get(ln_name + ".weight", {k_valid});
+    const HostTensor* b = get(ln_name + ".bias", {k_valid});
+    if (!g || !b) return Lin();
+    std::vector<float> wf((size_t)n_valid * k_valid), bf(n_valid), sv;
+    for (int n = 0; n < n_valid; ++n) {
+      double acc = bias ? (*bias)[n] : 0.0;
+      for (int k = 0; k < k_valid; ++k) {
+        const float w = rows[(size_t)n * k_valid + k];
+        wf[(size_t)n * k_valid + k] = w * g->data[k];
+        acc += (double)w * b->data[k];
+      }
+      bf[n] = (float)acc;
+    }
+    Lin L = pack(wf, n_valid, k_valid, &bf);
+    sv.assign((size_t)L.N, 0.f);
+    for (int n = 0; n < n_valid; ++n) {
+      double acc = 0.0;
+      for (int k = 0; k < k_valid; ++k) {
+        const uint32_t u = (uint32_t)f32_to_bf16_bits(wf[(size_t)n * k_valid + k]) << 16;
+        float r;
+        memcpy(&r, &u, 4);
+        acc += r;
+      }
+      sv[n] = (float)acc;
+    }
+    L.ln_s = upload(sv);
+    return L;
+  }
+  Lin linear_ln(const std::string& p, int out_f, int in_f, const std::string& ln_name) {
+    const HostTensor* w = get(p + ".weight", {out_f, in_f});
+    const HostTensor* b = get(p + ".bias", {out_f});
+    if (!w || !b) return Lin();
+    return pack_ln(w->data, out_f, in_f, &b->data, ln_name);
+  }
+
   Lin linear(const std::string& p, int out_f, int in_f, bool has_bias = true) {
     const HostTensor* w = get(p + ".weight", {out_f, in_f});
     const HostTensor* b = has_bias ? get(p + ".bias", {out_f}) : nullptr;
@@ -421,9 +460,11 @@ static int finalize_whisper(wfl_model* m, Packer& P) {
       }
       for (int j = 0; j < d; ++j) { bias[j] = bq->data[j] * qs; bias[2 * d + j] = bv->data[j]; }
       L.qkv = P.pack(rows, 3 * d, d, &bias);
+      L.qkv_ln = P.pack_ln(rows, 3 * d, d, &bias, p + "self_attn_layer_norm");
     }
     L.out = P.linear(p + "self_attn.out_proj", d, d);
     L.fc1 = P.linear(p + "fc1", a.enc_ffn, d);
+    L.fc1_ln = P.linear_ln(p + "fc1", a.enc_ffn, d, p + "final_layer_norm");
     L.fc2 = P.linear(p + "fc2", d, a.enc_ffn);
   }
   m->enc_ln = P.ln("encoder.layer_norm", d);
@@ -593,9 +634,11 @@ static int finalize_head(wfl_model* m, Packer& P) {
     ConfLayer& C = m->conf[i];
     C.ff1_ln = P.ln(p + "ff1.net.0", d);
     C.ff1_a = P.linear(p + "ff1.net.1", d * x, d);
+    C.ff1_a_ln = P.linear_ln(p + "ff1.net.1", d * x, d, p + "ff1.net.0");
     C.ff1_b = P.linear(p + "ff1.net.4", d, d * x);
     C.ff2_ln = P.ln(p + "ff2.net.0", d);
     C.ff2_a = P.linear(p + "ff2.net.1", d * x, d);
+    C.ff2_a_ln = P.linear_ln(p + "ff2.net.1", d * x, d, p + "ff2.net.0");
     C.ff2_b = P.linear(p + "ff2.net.4", d, d * x);
     const HostTensor* iw = P.get(p + "self_attn.in_proj_weight", {3 * d, d});
     const HostTensor* ib = P.get(p + "self_attn.in_proj_bias", {3 * d});
@@ -788,6 +831,7 @@ struct Runner {
             int clip_ld = 0) {
     if (rc) return;
     GemmArgs g{};
+    g.ln_s = W.ln_s; g.ln_eps = 1e-5f;
     g.A = A; g.lda = lda;
     g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
     g.W = W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.n_valid;
@@ -811,12 +855,34 @@ struct Runner {
     const int r = wfl_launch_gemm(g, s);
     if (m->prof_on) {
       (void)hipEventRecord(e1, s);
-      const int key = (act & 7) | (glu ? 8 : 0) | (out_f32 ? 16 : 0);
+      const int key = (act & 3) | (glu ? 4 : 0) | (out_f32 ? 8 : 0) | (res ? 16 : 0) | ((g_wfl_gemm_kernel_id & 7) << 5);
       m->prof.key.push_back(key);
       m->prof.launches[key] += 1;
       m->prof.flops[key] += 2.0 * (double)(M / P) * T * (double)W.n_valid * (double)W.K;
     }
     if (r) rc = fail(r, "gemm launch failed (" + std::to_string(r) + ")");
+  }
+
+  // y = act(LayerNorm(x) W^T + b): one launch with the LayerNorm folded into the GEMM when the streaming kernel takes the
+  // shape (gemm_stream.hip), else the LayerNorm kernel into `scratch` followed by the plain GEMM.
+  void ln_gemm(const bf16_t* x, bf16_t* scratch, const LNp& w, const Lin& plain, const Lin& folded, int M, void* C, long ldc,
+               int act) {
+    if (rc) return;
+    // Off by default: measured on MI355X (tools/gemm_lab.py, qkvLN / fc1LN) the in-kernel statistics cost ~3.5 us per
+    // 192-row tile, i.e. more than the 11.4 us LayerNorm launch they replace on the 16 x 30 s workload.  WFL_LN_FOLD=1 turns
+    // the folded path on (parity-tested either way).
+    static int fold = -1;
+    if (fold < 0) { const char* e = getenv("WFL_LN_FOLD"); fold = e && atoi(e) ? 1 : 0; }
+    if (fold && folded.ln_s) {
+      GemmArgs g{};
+      g.M = M; g.N = folded.N; g.K = folded.K; g.cin = folded.K; g.n_valid = folded.n_valid; g.act = act; g.ln_s = folded.ln_s;
+      if (wfl_gemm_stream_takes(g)) {
+        gemm(x + (long)p.lead * p.d, p.d, folded, M, p.P, p.T, C, ldc, p.lead, p.P, act);
+        return;
+      }
+    }
+    ln(x, scratch, w);
+    gemm(scratch + (long)p.lead * p.d, p.d, plain, M, p.P, p.T, C, ldc, p.lead, p.P, act);
   }
 
   void ln(const bf16_t* x, bf16_t* y, const LNp& w) {
@@ -924,12 +990,10 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
            1.f, 0, 0, false, false, m->pos, d);
     for (int i = 0; i < a.enc_layers; ++i) {
       const EncLayer& L_ = m->enc[i];
-      R.ln(X, Y, L_.ln1);
-      R.gemm(Y + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
+      R.ln_gemm(X, Y, L_.ln1, L_.qkv, L_.qkv_ln, (int)Mrows, QK, 3 * d, WFL_ACT_NONE);
       R.attn(a.enc_heads);
       R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
-      R.ln(X, Y, L_.ln2);
-      R.gemm(Y + (long)p.lead * d, d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.ln_gemm(X, Y, L_.ln2, L_.fc1, L_.fc1_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
     }
     R.ln(X, Y, m->enc_ln);       // encoder output in Y
@@ -1081,8 +1145,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     for (int i = 0; i < a.n_conformer; ++i) {
       const ConfLayer& C = m->conf[i];
       // x = x + 0.5 * FF1(x)
-      R.ln(H, S, C.ff1_ln);
-      R.gemm(S + (long)p.lead * d, d, C.ff1_a, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.ln_gemm(H, S, C.ff1_ln, C.ff1_a, C.ff1_a_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff1_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
       // x = LN1(x + MHA(x))
       R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
@@ -1095,8 +1158,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
       R.gemm(ATT + (long)(p.lead - a.conformer_kernel / 2) * d, d, C.conv, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU);
       R.gemm(S + (long)p.lead * d, d, C.pw2, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
       // x = x + 0.5 * FF2(x)
-      R.ln(H, S, C.ff2_ln);
-      R.gemm(S + (long)p.lead * d, d, C.ff2_a, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.ln_gemm(H, S, C.ff2_ln, C.ff2_a, C.ff2_a_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff2_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
     }
     if (a.enable_dilated) {
@@ -1223,7 +1285,7 @@ int32_t wfl_gemm_profile_enable(wfl_model* m, int32_t on) {
 int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys, int64_t* launches, double* total_ms,
                               double* total_flops, int32_t* n_variants, int32_t reset) {
   if (!m || !keys || !launches || !total_ms || !total_flops || !n_variants) return fail(-1, "wfl_gemm_profile_read: null argument");
-  double ms[64] = {0};
+  double ms[256] = {0};
   for (size_t i = 0; i < m->prof_used; ++i) {
     HIPCHK(hipEventSynchronize(m->prof.ev[i].second));
     float t = 0;
@@ -1231,7 +1293,7 @@ int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys,
     ms[m->prof.key[i]] += t;
   }
   int n = 0;
-  for (int k = 0; k < 64 && n < max_variants; ++k)
+  for (int k = 0; k < 256 && n < max_variants; ++k)
     if (m->prof.launches[k]) {
       keys[n] = k; launches[n] = m->prof.launches[k]; total_ms[n] = ms[k]; total_flops[n] = m->prof.flops[k];
       ++n;

@@ -270,7 +270,7 @@ class BIOPhonemeTagger:
         _lib.check(self._lib.wfl_gemm_profile_enable(self._handle, int(on)), "wfl_gemm_profile_enable")
 
     def gemm_profile_read(self, reset=True):
-        n = 64
+        n = 256
         keys = (C.c_int32 * n)()
         launches = (C.c_int64 * n)()
         ms = (C.c_double * n)()
