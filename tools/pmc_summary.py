@@ -32,7 +32,7 @@ def main():
         fetch = 2 * v / n / 1024
         write = wv / max(wn, 1) / 1024
         out["kernels"][k] = {"launches": n, "fetch_mb": round(fetch, 2), "write_mb": round(write, 2), "hbm_mb": round(fetch + write, 2)}
-        if k.startswith("void gemm_bf16_kernel"):
+        if k.startswith(("void gemm_bf16_kernel", "void gemm256_kernel", "void gemm_stream_kernel")):
             g_n += n
             g_b += n * (fetch + write)
     out["gemm_family_hbm_mb_per_launch"] = round(g_b / max(g_n, 1), 2)
