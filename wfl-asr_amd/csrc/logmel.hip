@@ -3,11 +3,11 @@
 // n_samples, centred STFT (n_fft 400, hop 160, periodic Hann, reflect pad 200), power, Slaney mel, log10
 // (clamp 1e-10), per-clip floor (max - 8), (x + 4) / 4.
 //
-// Kernel 1 (one workgroup = 64 frames of one clip): the 400-point real DFT is a GEMM
-//   [64 frames x 400 samples] . [400 x 2*201 (Hann-folded cos | -sin)]
+// Kernel 1 (one workgroup = FT = 32 frames of one clip): the 400-point real DFT is a GEMM
+//   [FT frames x 400 samples] . [400 x 2*201 (Hann-folded cos | -sin)]
 // run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, so fp32 like torch.stft).
 // The frames operand is Toeplitz (frame f, sample n = signal[160 f + n]), so the workgroup stages only the
-// 10 480-sample signal segment in LDS, skewed by one word per 160 samples so that the 32 frames a fragment
+// 5 360-sample signal segment in LDS, skewed by one word per 160 samples so that the 32 frames a fragment
 // read touches fall in 32 different banks.  Power spectra go through LDS to the sparse mel projection
 // (each bin feeds <= 2 triangles), log10, and an ordered-int atomic max per clip.
 // Kernel 2 applies the per-clip floor + affine and writes bf16 channels-last frame rows (the Whisper stem's
@@ -17,8 +17,10 @@
 #define NFFT 400
 #define HOP 160
 #define NBIN_PAD 224     // 201 bins padded to 7 MFMA column tiles
-#define FT 64            // frames per workgroup
-#define SEG (63 * HOP + NFFT)              // 10480 samples
+#define FT 32            // frames per workgroup: 50 KB of LDS, so three workgroups share a CU and one's staging /
+                         // mel phases run under the others' MFMA loops (64 frames = 100 KB = one per CU ran 2x slower)
+#define RT (FT / 32)     // 32-frame MFMA row tiles per workgroup
+#define SEG ((FT - 1) * HOP + NFFT)        // 5360 samples
 #define SEG_LDS (SEG + SEG / HOP + 2)      // skewed
 #define PPITCH 225
 
@@ -51,13 +53,25 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   const float* w = p.wav + (long)b * p.ldw;
 
   // ---- stage the signal segment: sample index i = 160*f0 - 200 + j, reflect about 0 and n_samples-1
+  // All 41 loads of a thread are issued before the first LDS write (unconditional, index clamped, value selected afterwards):
+  // a load-then-store loop serialises 41 HBM round trips per workgroup (it was 2/3 of this kernel's time).
   const int s0 = f0 * HOP - NFFT / 2;
-  for (int j = tid; j < SEG; j += 256) {
-    int i = s0 + j;
+  constexpr int NIT = (SEG + 255) / 256;
+  float sv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int i = s0 + tid + 256 * it;
     if (i < 0) i = -i;
     if (i >= p.n_samples) i = 2 * (p.n_samples - 1) - i;
-    const float v = (i >= 0 && i < len) ? w[i] : 0.f;
-    seg[j + j / HOP] = v;
+    const bool ok = i >= 0 && i < len;
+    const int ic = min(max(i, 0), p.L - 1);
+    const float v = w[ic];
+    sv[it] = ok ? v : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int j = tid + 256 * it;
+    if (j < SEG) seg[j + j / HOP] = sv[it];
   }
   __syncthreads();
 
@@ -69,43 +83,55 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   // instead of 200.  The twiddle rows come from L2 through a register ring PD steps deep (one wave per SIMD has
   // nobody else to hide a ~1 us L2 round trip).
   const int r = lane & 31, kh = lane >> 5;
-  constexpr int PD = 10;                       // prefetch depth in K-steps; 100 steps = 10 rounds of PD
+  constexpr int PD = 20;                       // prefetch depth in K-steps (2 MFMAs = 128 cycles each); 100 steps = 5 rounds of PD
   for (int ct = wid; ct < NBIN_PAD / 32; ct += 4) {
-    f32x16 re[2], im[2];
+    f32x16 re[RT], im[RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { re[rt][e] = 0.f; im[rt][e] = 0.f; }
-    const float* fa = seg + 161 * r;                         // frame r of row tile 0 (skewed: + n + n/160)
-    const float* fb = seg + 161 * (r + 32);
+    const float* fa = seg + 161 * r;                         // frame r of row tile 0 (skewed: + n + n/160); tile rt at + 161*32*rt
     const float* bc = p.Wc + (long)kh * NBIN_PAD + ct * 32 + r;   // row j-1 of the folded tables, j = 1 + 2*step + kh
     const float* bs = p.Ws + (long)kh * NBIN_PAD + ct * 32 + r;
     float wcv[PD], wsv[PD];
 #pragma unroll
     for (int q = 0; q < PD; ++q) { wcv[q] = bc[(long)(2 * q) * NBIN_PAD]; wsv[q] = bs[(long)(2 * q) * NBIN_PAD]; }
+    // the signal samples of a K-step are read from LDS one step ahead of the MFMAs that consume them
+    auto ldx = [&](int step, float (&xa)[RT], float (&xb)[RT]) __attribute__((always_inline)) {
+      const int j = 1 + 2 * step + kh;                       // 1..200
+      const int n2 = NFFT - j;                               // 200..399
+      const int a1 = j + (j >= 160 ? 1 : 0);
+      const int a2 = n2 + (n2 >= 320 ? 2 : 1);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { xa[rt] = fa[161 * 32 * rt + a1]; xb[rt] = fa[161 * 32 * rt + a2]; }
+    };
+    float na[RT], nb[RT];
+    ldx(0, na, nb);
     for (int sb = 0; sb < 100; sb += PD) {
 #pragma unroll
       for (int q = 0; q < PD; ++q) {
         const int step = sb + q;
-        const int j = 1 + 2 * step + kh;                     // 1..200
-        const int n2 = NFFT - j;                             // 200..399
-        const int a1 = j + (j >= 160 ? 1 : 0);
-        const int a2 = n2 + (n2 >= 320 ? 2 : 1);
-        const float x0a = fa[a1], x0b = fa[a2], x1a = fb[a1], x1b = fb[a2];
+        float xa[RT], xb[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { xa[rt] = na[rt]; xb[rt] = nb[rt]; }
         const float c = wcv[q], sn = wsv[q];
-        if (step + PD < 100) {
+        __builtin_amdgcn_sched_barrier(0);            // pin the prefetches here: hipcc otherwise sinks the twiddle loads to
+        if (step + PD < 100) {                         // their use PD steps later and every step eats an L2 round trip
           wcv[q] = bc[(long)(2 * (step + PD)) * NBIN_PAD];
           wsv[q] = bs[(long)(2 * (step + PD)) * NBIN_PAD];
         }
-        re[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0a + x0b, c, re[0], 0, 0, 0);
-        im[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0a - x0b, sn, im[0], 0, 0, 0);
-        re[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1a + x1b, c, re[1], 0, 0, 0);
-        im[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1a - x1b, sn, im[1], 0, 0, 0);
+        if (step + 1 < 100) ldx(step + 1, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          re[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[rt] + xb[rt], c, re[rt], 0, 0, 0);
+          im[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[rt] - xb[rt], sn, im[rt], 0, 0, 0);
+        }
       }
     }
     // D[row][col]: col = lane&31 (bin), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (frame in the row tile)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int fr = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -114,13 +140,25 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   }
   __syncthreads();
 
-  // ---- sparse mel projection + log10; thread -> frame (tid & 63), mel bands (tid >> 6) + 4*i
-  const int f = tid & 63;
+  // ---- sparse mel projection + log10; thread -> frame (tid % FT), mel bands (tid / FT) + (256 / FT) * i.
+  // The filter table (weights, first bin, width per band: ~10 KB) moves into the now idle signal segment first: read from
+  // global memory inside the band loop, every tap was a dependent L2 round trip (~1/3 of this kernel's time).
+  const int f = tid % FT;
   const bool fvalid = f0 + f < p.n_frames;
   float mx = -INFINITY;
-  for (int m = tid >> 6; m < p.n_mels; m += 4) {
-    const int lo = p.mel_lo[m], cnt = p.mel_cnt[m];
-    const float* mw = p.mel_w + (long)m * p.mel_maxw;
+  const int nw = p.n_mels * p.mel_maxw;
+  const bool tab_lds = nw + 2 * p.n_mels <= SEG_LDS;
+  float* lw = seg;
+  int* llo = (int*)(seg + nw);
+  int* lcnt = llo + p.n_mels;
+  if (tab_lds) {
+    for (int i = tid; i < nw; i += 256) lw[i] = p.mel_w[i];
+    for (int i = tid; i < p.n_mels; i += 256) { llo[i] = p.mel_lo[i]; lcnt[i] = p.mel_cnt[i]; }
+    __syncthreads();
+  }
+  for (int m = tid / FT; m < p.n_mels; m += 256 / FT) {
+    const int lo = tab_lds ? llo[m] : p.mel_lo[m], cnt = tab_lds ? lcnt[m] : p.mel_cnt[m];
+    const float* mw = tab_lds ? lw + m * p.mel_maxw : p.mel_w + (long)m * p.mel_maxw;
     float acc = 0.f;
     for (int i = 0; i < cnt; ++i) acc += mw[i] * pw[f * PPITCH + lo + i];
     const float lv = log10f(fmaxf(acc, 1e-10f));
