@@ -47,7 +47,9 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 #define SSTAMP(k) do { } while (0)
 #endif
 
-template <int ACT, int MT, bool RES, bool LNF>
+// LNF: 0 no LayerNorm, 1 folded with statistics summed in the kernel, 2 folded with statistics read from p.stats_in.
+// STATS: the (residual) epilogue also writes p.stats_out for the next LayerNorm-folded consumer.
+template <int ACT, int MT, bool RES, int LNF, bool STATS>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   constexpr int BMV = MT * 32;                    // frame rows per tile
 #ifdef WFL_LAB_STB32
@@ -57,9 +59,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   constexpr int STB = (BMV + 256) * SBK * 2;      // stage bytes: frame tile then weight tile
   constexpr int WOFF = BMV * SBK * 2;
 #endif
-  constexpr int NSTORE = 2 * MT;                  // epilogue stores per wave
+  constexpr int NSTORE = 2 * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around)
+  constexpr int SROW = 4;                             // float2 slots per row of the statistics buffer (one per 256-column tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* stat_lds = (float*)(smem + SNST * STB);  // [2 groups][MT*16 rows][2]
+  float* stat_lds = (float*)(smem + SNST * STB);  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       }
     }
     float mu[LNF ? MT : 1], rs[LNF ? MT : 1];
-    if (LNF) {
+    if (LNF == 1) {
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
         const float2 s = *(const float2*)(stat_lds + (grp * (MT * 16) + u * 16 + c) * 2);
@@ -203,7 +206,31 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         rs[u] = s.y;
       }
     }
+    if (LNF == 2) {
+      // the producer left (sum, sum of squares) per 256-column tile of every row, SROW slots per row; slots are added in a
+      // fixed order, the unused ones masked (all loads are issued before the first use)
+      f32x4 sp[MT][2];
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        int m = m0 + wm + 16 * u + c;
+        m = m < p.M ? m : p.M - 1;
+        const f32x4* q = (const f32x4*)(p.stats_in + (p.stats_lead + m) * (2 * SROW));
+        sp[u][0] = q[0];
+        sp[u][1] = q[1];
+      }
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        float a1 = sp[u][0][0], a2 = sp[u][0][1];
+        if (p.stats_nsl > 1) { a1 += sp[u][0][2]; a2 += sp[u][0][3]; }
+        if (p.stats_nsl > 2) { a1 += sp[u][1][0]; a2 += sp[u][1][1]; }
+        if (p.stats_nsl > 3) { a1 += sp[u][1][2]; a2 += sp[u][1][3]; }
+        const float mean = a1 / (float)p.K;
+        mu[u] = mean;
+        rs[u] = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+      }
+    }
     char* trash = (char*)p.trash + lane * 16;
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
       __builtin_amdgcn_sched_barrier(0);            // one 16-frame tile at a time: keeps the register footprint bounded
@@ -226,12 +253,48 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
         dst = (orow[u] >= 0 && nb + 32 * h < p.n_valid) ? dst : trash;
         *(bf16x8*)dst = o;
+        if (STATS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float r = bf2f(o[e]); t1 += r; t2 = fmaf(r, r, t2); }
+        }
+      }
+      if (STATS) {                                   // this wave's 64 columns of frame c: add the four lane groups; the
+        t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);   // partial goes to this wave's LDS slot
+        t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+        if (g == 0) *(float2*)(stat_lds + (((grp * 4 + wq) * (MT * 16)) + u * 16 + c) * 2) = float2{t1, t2};
+        t1 = t2 = 0.f;
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (STATS) {
+      // The last of the group's four waves to get here adds the four partials of every row in a fixed order (bit-exact
+      // whatever the arrival order) and writes (sum, sum of squares) for this 256-column tile; the others send their MT
+      // stores to the scratch line so every wave's store count stays the same.  No barrier: LDS executes the group's
+      // writes, the counter atomics and the reads in issue order, and a wave drains its writes before it takes a ticket.
+      unsigned* cnt = (unsigned*)(stat_lds + 8 * (MT * 16) * 2) + grp;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      unsigned ticket = 0;
+      if (lane == 0) ticket = atomicAdd(cnt, 1u);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      const bool last = ticket == 3;
+      if (last && lane == 0) *cnt = 0;
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          const float2 v = *(const float2*)(stat_lds + (((grp * 4 + w4) * (MT * 16)) + u * 16 + c) * 2);
+          a1 += v.x; a2 += v.y;
+        }
+        float* sd = p.stats_out + ((long)orow[u] * SROW + (n0 >> 8)) * 2;
+        sd = (last && orow[u] >= 0 && g == 0) ? sd : (float*)trash;
+        *(float2*)sd = float2{a1, a2};
+      }
+    }
   };
 
+  if (STATS && tid < 2) ((unsigned*)(stat_lds + 8 * (MT * 16) * 2))[tid] = 0;   // the groups' arrival counters
   // ---- prologue: three stages in flight, stage 0 landed, group 1 one barrier behind
 #pragma unroll
   for (int t = 0; t < SNST - 1; ++t) prefetch_one();
@@ -258,7 +321,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     for (int u = 0; u < MT; ++u) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
-      if (LNF) {
+      if (LNF == 1) {
         if ((u & 3) == wq) {                         // wave-uniform
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -308,11 +371,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
       SSB();
       mma_all();
-      if (LNF && kt == nk - 1) ln_publish();
+      if (LNF == 1 && kt == nk - 1) ln_publish();
       SSB();
       if (!grp) wait_stage(s + 1, have_prev && kt < 2);
-      if (LNF) __builtin_amdgcn_s_waitcnt(0xC07F);   // the statistics are in LDS before the barrier
-      if (LNF || !(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
+      if (LNF == 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // the statistics are in LDS before the barrier
+      if (LNF == 1 || !(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
       SSB();
       ++s;
     };
@@ -346,21 +409,21 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   SSTAMP(2);
   SSTAMP(3);
   if (have_prev) epilogue(pm0, pn0);
-  if (LNF && !grp) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+  if (LNF == 1 && !grp) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
   SSTAMP(4);
 #undef SSB
 }
 
-template <int ACT, int MT, bool RES, bool LNF>
+template <int ACT, int MT, bool RES, int LNF, bool STATS>
 static int launch_stream(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
 #ifdef WFL_LAB_STB32
-  constexpr int lds = SNST * 512 * SBK * 2 + 2 * (MT * 16) * 2 * 4;
+  constexpr int lds = SNST * 512 * SBK * 2 + 8 * (MT * 16) * 2 * 4 + 64;
 #else
-  constexpr int lds = SNST * (BMV + 256) * SBK * 2 + 2 * (MT * 16) * 2 * 4;
+  constexpr int lds = SNST * (BMV + 256) * SBK * 2 + 8 * (MT * 16) * 2 * 4 + 64;
 #endif
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
-  auto k = gemm_stream_kernel<ACT, MT, RES, LNF>;
+  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
@@ -375,14 +438,14 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
 // it saves a whole round, and hipcc (ROCm 7.2) cannot hold its 128 accumulators + 48 fragment registers + the epilogue
 // state in 256 VGPRs without spilling into the K loop (measured: fc1 124 us with the spilling 256-row build, 74 us with
 // 192 rows).  WFL_GEMM_BM=256 still selects it for experiments.
-template <int ACT, bool RES, bool LNF>
+template <int ACT, bool RES, int LNF, bool STATS = false>
 static int launch_stream_mt(const GemmArgs& a, hipStream_t s) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0; }
 #ifdef WFL_STREAM_MT8
-  if (forced == 256) return launch_stream<ACT, 8, RES, LNF>(a, s);
+  if (forced == 256) return launch_stream<ACT, 8, RES, LNF, STATS>(a, s);
 #endif
-  return launch_stream<ACT, 6, RES, LNF>(a, s);
+  return launch_stream<ACT, 6, RES, LNF, STATS>(a, s);
 }
 
 // The launches this kernel takes (everything else stays with gemm256 / gemm).
@@ -395,9 +458,10 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
 #endif
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
   if (a.N % 256 || a.K % SBK || a.cin % SBK || a.K / SBK < 8 || a.n_valid % 8) return false;
-  // a folded LayerNorm must not depend on the batch (a clip labelled alone has to equal the same clip inside a batch bit for
-  // bit); the plain launches are bit-identical across the three GEMM kernels, so small ones may go to the 128x128 tile
-  if (!a.ln_s && a.M < 2048) return false;
+  // (no lower bound on M: a LayerNorm folded through the producer's statistics must not depend on the batch size -- a clip
+  // labelled alone has to equal the same clip inside a batch bit for bit)
+  if (a.stats_out && (!a.res || a.N / 256 > 4)) return false;          // 4 tile slots per row of the statistics buffer
+  if (a.stats_in && (!a.ln_s || a.stats_nsl <= 0 || a.stats_nsl > 4)) return false;
   if (a.res && a.act != WFL_ACT_NONE) return false;
   if (a.ln_s && (a.res || a.cin < a.K || (a.act != WFL_ACT_NONE && a.act != WFL_ACT_GELU))) return false;
   if (a.act == WFL_ACT_SIGMOID) return false;
@@ -414,17 +478,24 @@ int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {
   GemmArgs g = a;
   g.trash = trash;
   if (g.ln_s) {
+    if (g.stats_in) {
+      switch (g.act) {
+        case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, 2>(g, s);
+        case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, 2>(g, s);
+      }
+      return 1;
+    }
     switch (g.act) {
-      case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, true>(g, s);
-      case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, true>(g, s);
+      case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, 1>(g, s);
+      case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, 1>(g, s);
     }
     return 1;
   }
-  if (g.res) return launch_stream_mt<WFL_ACT_NONE, true, false>(g, s);
+  if (g.res) return g.stats_out ? launch_stream_mt<WFL_ACT_NONE, true, 0, true>(g, s) : launch_stream_mt<WFL_ACT_NONE, true, 0>(g, s);
   switch (g.act) {
-    case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, false>(g, s);
-    case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, false>(g, s);
-    case WFL_ACT_RELU: return launch_stream_mt<WFL_ACT_RELU, false, false>(g, s);
+    case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, 0>(g, s);
+    case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, 0>(g, s);
+    case WFL_ACT_RELU: return launch_stream_mt<WFL_ACT_RELU, false, 0>(g, s);
   }
   return 1;
 }

@@ -727,7 +727,7 @@ struct Plan {
   int nlev, Tl[8], Pl[8], leadl[8];
   long Rl[8];
   // byte offsets
-  long mel, c1, X, Y, ATT, QK, FF, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
+  long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
   long FA, FB, XG, gate, rtab, wstats, cstats, total;
 };
 
@@ -786,6 +786,7 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
   p.ATT = take(p.R * p.d * 2);
   p.QK = take(p.R * 3 * p.d * 2);                   // packed q | k | v rows
   p.FF = take(p.R * p.ffw * 2);
+  p.stats = take(p.R * 4L * 2 * 4);                     // per row, per 256-column tile (<= 4): (sum, sum of squares)
   p.enc2 = take(p.R * p.d * 2);
   p.clipmax = take((long)B * 4);
   p.logits = take((long)B * p.T * a.num_classes * 4);
@@ -823,6 +824,10 @@ struct Runner {
   int rc = 0;
 
   bf16_t* buf(long off) const { return (bf16_t*)(ws + off); }
+  // LayerNorm statistics left behind by the last residual GEMM (gemm_stream.hip, STATS): valid for the rows of `stats_for`
+  const void* stats_for = nullptr;
+  int stats_nsl = 0;
+  bool stats_in_next = false;   // the next gemm() call (a folded operand) reads them
 
   void gemm(const bf16_t* A, long lda, const Lin& W, int M, int P, int T, void* C, long ldc, long c_lead, int c_pitch,
             int act = WFL_ACT_NONE, const bf16_t* res = nullptr, long ldres = 0, float alpha = 1.f, int cin = 0,
@@ -832,6 +837,8 @@ struct Runner {
     if (rc) return;
     GemmArgs g{};
     g.ln_s = W.ln_s; g.ln_eps = 1e-5f;
+    if (W.ln_s && stats_in_next) { g.stats_in = (const float*)(ws + p.stats); g.stats_nsl = stats_nsl; g.stats_lead = p.lead; }
+    stats_in_next = false;
     g.A = A; g.lda = lda;
     g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
     g.W = W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.n_valid;
@@ -841,6 +848,13 @@ struct Runner {
     g.res = res; g.ldres = ldres; g.alpha = alpha;
     g.pos = pos; g.ldpos = ldpos;
     g.act = act; g.glu = glu ? 1 : 0; g.out_f32 = out_f32 ? 1 : 0;
+    if (C == stats_for) stats_for = nullptr;                       // the rows they describe are being overwritten
+    if (res && !out_f32 && !glu && act == WFL_ACT_NONE && ldc == p.d && W.n_valid == p.d && c_lead == p.lead && c_pitch == p.P &&
+        P == p.P && ln_fold_mode() == 1) {
+      g.stats_out = (float*)(ws + p.stats);
+      if (wfl_gemm_stream_takes(g)) { stats_for = C; stats_nsl = W.N / 256; }
+      else g.stats_out = nullptr;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->prof_on) {
       if (m->prof_used >= m->prof.ev.size()) {
@@ -863,20 +877,25 @@ struct Runner {
     if (r) rc = fail(r, "gemm launch failed (" + std::to_string(r) + ")");
   }
 
-  // y = act(LayerNorm(x) W^T + b): one launch with the LayerNorm folded into the GEMM when the streaming kernel takes the
-  // shape (gemm_stream.hip), else the LayerNorm kernel into `scratch` followed by the plain GEMM.
+  // WFL_LN_FOLD: 1 (default) fold a LayerNorm into the GEMM that consumes it whenever the GEMM that produced its input left
+  // the row statistics behind; 2 fold always, summing the statistics inside the consumer (slower: tools/gemm_lab.py qkvLN);
+  // 0 never (LayerNorm kernel + plain GEMM).
+  static int ln_fold_mode() {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("WFL_LN_FOLD"); mode = e ? atoi(e) : 1; }
+    return mode;
+  }
+  // y = act(LayerNorm(x) W^T + b)
   void ln_gemm(const bf16_t* x, bf16_t* scratch, const LNp& w, const Lin& plain, const Lin& folded, int M, void* C, long ldc,
                int act) {
     if (rc) return;
-    // Off by default: measured on MI355X (tools/gemm_lab.py, qkvLN / fc1LN) the in-kernel statistics cost ~3.5 us per
-    // 192-row tile, i.e. more than the 11.4 us LayerNorm launch they replace on the 16 x 30 s workload.  WFL_LN_FOLD=1 turns
-    // the folded path on (parity-tested either way).
-    static int fold = -1;
-    if (fold < 0) { const char* e = getenv("WFL_LN_FOLD"); fold = e && atoi(e) ? 1 : 0; }
-    if (fold && folded.ln_s) {
+    const int mode = ln_fold_mode();
+    if (folded.ln_s && (mode == 2 || (mode == 1 && stats_for == x))) {
       GemmArgs g{};
       g.M = M; g.N = folded.N; g.K = folded.K; g.cin = folded.K; g.n_valid = folded.n_valid; g.act = act; g.ln_s = folded.ln_s;
+      if (mode == 1) { g.stats_in = (const float*)(ws + p.stats); g.stats_nsl = stats_nsl; }
       if (wfl_gemm_stream_takes(g)) {
+        stats_in_next = mode == 1;
         gemm(x + (long)p.lead * p.d, p.d, folded, M, p.P, p.T, C, ldc, p.lead, p.P, act);
         return;
       }
@@ -887,6 +906,7 @@ struct Runner {
 
   void ln(const bf16_t* x, bf16_t* y, const LNp& w) {
     if (rc) return;
+    if (y == stats_for) stats_for = nullptr;
     const int r = wfl_launch_layernorm(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, s);
     if (r) rc = fail(r, "layernorm launch failed");
   }
@@ -1089,6 +1109,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     }
     if (stable) { R.ln(H, S, m->wenc_ln); std::swap(H, S); }
     if (H != Y && !R.rc) {                             // the head expects the encoder output in Y
+      R.stats_for = nullptr;
       HIPCHK(hipMemcpyAsync(Y, H, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
     }
   }
@@ -1136,6 +1157,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
         LstmArgs la{};
         la.gx = GX; la.ldgx = 8 * Hh; la.whh = m->lstm_whh[layer]; la.out = S; la.ldo = d; la.lead = p.lead;
         la.B = B; la.T = p.T; la.P = p.P; la.H = Hh; la.U = m->lstm_U;
+        R.stats_for = nullptr;
         const int lr = wfl_launch_lstm(la, R.ws + p.lstm_x, R.s);
         if (lr) return fail(lr, lr == -5 ? "BiLSTM: batch too large for one resident launch (max 256 / (2 * H/U) groups of 16 clips)"
                                           : "lstm launch failed (" + std::to_string(lr) + ")");
