@@ -133,9 +133,10 @@ struct ConfLayer {
 };
 
 // GEMM launches are timed per kernel variant (template instantiation), keyed act | glu<<2 | out_f32<<3 | res<<4 | kernel id<<5
+// | LayerNorm-fold mode<<8 | statistics-emitting epilogue<<10
 struct GemmProf {
-  long launches[256] = {0};
-  double flops[256] = {0};
+  long launches[2048] = {0};
+  double flops[2048] = {0};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<int> key;
 };
@@ -869,7 +870,8 @@ struct Runner {
     const int r = wfl_launch_gemm(g, s);
     if (m->prof_on) {
       (void)hipEventRecord(e1, s);
-      const int key = (act & 3) | (glu ? 4 : 0) | (out_f32 ? 8 : 0) | (res ? 16 : 0) | ((g_wfl_gemm_kernel_id & 7) << 5);
+      const int key = (act & 3) | (glu ? 4 : 0) | (out_f32 ? 8 : 0) | (res ? 16 : 0) | ((g_wfl_gemm_kernel_id & 7) << 5) |
+                      ((g.ln_s ? (g.stats_in ? 2 : 1) : 0) << 8) | (g.stats_out ? 1024 : 0);
       m->prof.key.push_back(key);
       m->prof.launches[key] += 1;
       m->prof.flops[key] += 2.0 * (double)(M / P) * T * (double)W.n_valid * (double)W.K;
@@ -1307,7 +1309,7 @@ int32_t wfl_gemm_profile_enable(wfl_model* m, int32_t on) {
 int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys, int64_t* launches, double* total_ms,
                               double* total_flops, int32_t* n_variants, int32_t reset) {
   if (!m || !keys || !launches || !total_ms || !total_flops || !n_variants) return fail(-1, "wfl_gemm_profile_read: null argument");
-  double ms[256] = {0};
+  std::vector<double> ms(2048, 0.0);
   for (size_t i = 0; i < m->prof_used; ++i) {
     HIPCHK(hipEventSynchronize(m->prof.ev[i].second));
     float t = 0;
@@ -1315,7 +1317,7 @@ int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys,
     ms[m->prof.key[i]] += t;
   }
   int n = 0;
-  for (int k = 0; k < 256 && n < max_variants; ++k)
+  for (int k = 0; k < 2048 && n < max_variants; ++k)
     if (m->prof.launches[k]) {
       keys[n] = k; launches[n] = m->prof.launches[k]; total_ms[n] = ms[k]; total_flops[n] = m->prof.flops[k];
       ++n;

@@ -48,6 +48,7 @@ class BIOPhonemeTagger:
         self._handle = C.c_void_p(0)
         self._ready = False
         self._ws = None
+        self._ws_extra = {}
         self._graphs = {}
         a = _lib.WflArch()
         a.abi_version = _lib.ABI_VERSION
@@ -107,10 +108,15 @@ class BIOPhonemeTagger:
     def num_frames(self, L: int) -> int:
         return int(self._lib.wfl_num_frames(self._handle, int(L)))
 
-    def _workspace(self, B: int, L: int, device):
+    def _workspace(self, B: int, L: int, device, slot: int = 0):
         need = int(self._lib.wfl_workspace_bytes(self._handle, B, L))
         if need <= 0:
             raise _lib.WflError("wfl_workspace_bytes failed")
+        if slot:                                    # extra workspaces: one per batch in flight on its own stream
+            ws = self._ws_extra.get(slot)
+            if ws is None or ws.numel() < need or ws.device != device:
+                self._ws_extra[slot] = ws = torch.empty(need, dtype=torch.uint8, device=device)
+            return ws
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             if self._graphs:
                 raise _lib.WflError("workspace must not grow while captured graphs hold its address; "
@@ -131,9 +137,9 @@ class BIOPhonemeTagger:
             raise ValueError("lang_id must have one entry per clip")
         return t
 
-    def _launch(self, x, lens_t, lang_t, mode, threshold, out: "TagBatch"):
+    def _launch(self, x, lens_t, lang_t, mode, threshold, out: "TagBatch", slot: int = 0):
         B, L = x.shape
-        ws = self._workspace(B, L, x.device)
+        ws = self._workspace(B, L, x.device, slot)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             rc = self._lib.wfl_forward(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(lang_t), mode,
@@ -159,13 +165,16 @@ class BIOPhonemeTagger:
     @torch.no_grad()
     def label(self, input_values: torch.Tensor, lang_id=None, threshold: float = 0.0, lens=None,
               average_languages: bool = False, want_logits: bool = False, want_hidden: bool = False,
-              graph: bool = False) -> TagBatch:
+              graph: bool = False, slot: int = 0) -> TagBatch:
         """The batched fast path: [B, L] fp32 16 kHz clips -> per-frame decisions (all on the GPU).
 
         graph=True (experimental, off by default everywhere) replays the whole forward (about 100 kernel launches)
         as one captured HIP graph per (B, L, mode) signature; inputs are copied into static buffers and the returned
         tensors are the graph's static outputs (consume them before the next call with the same signature).  The
-        kernels are long enough that eager launches already keep the GPU busy (graph gain measured < 1 %)."""
+        kernels are long enough that eager launches already keep the GPU busy (graph gain measured < 1 %).
+
+        slot: workspace index.  Batches labelled concurrently on different streams must use different slots (each slot owns
+        a workspace); the forward itself keeps no other per-call state."""
         if not self._ready:
             raise _lib.WflError("load_state_dict() has not been called")
         if not input_values.is_cuda:
@@ -193,7 +202,7 @@ class BIOPhonemeTagger:
             lang_d = lang_t.to(dev).contiguous() if lang_t is not None else None
             lens_d = lens_t.to(dev).contiguous() if lens_t is not None else None
             out = self._alloc_out(B, T, dev, want_logits, want_hidden)
-            self._launch(x, lens_d, lang_d, mode, threshold, out)
+            self._launch(x, lens_d, lang_d, mode, threshold, out, slot)
             return out
         key = (B, L, mode, float(threshold), want_logits, want_hidden, lens_t is not None, dev.index)
         g = self._graphs.get(key)
