@@ -150,11 +150,28 @@ int32_t wfl_op_tag_decide(const float* logits, int64_t ldl, int32_t rows, int32_
 
 /* Per-kernel timing hook for bench.py's roofline: when enabled, wfl_forward brackets every GEMM launch with
  * hipEvents on `stream`.  wfl_gemm_profile_read synchronises on them and returns, per GEMM kernel variant
- * (key = act | glu<<3 | out_f32<<4 | vt<<5, one template instantiation = one rocprof kernel name), the launch
+ * (key = act | glu<<2 | out_f32<<3 | res<<4 | kernel<<5 | ln_fold<<8 | stats<<10, one template instantiation = one
+ * rocprof kernel name), the launch
  * count, summed milliseconds and summed algorithmic FLOPs (2 * valid_rows * n_valid * K) since the last reset. */
 int32_t wfl_gemm_profile_enable(wfl_model* m, int32_t on);
 int32_t wfl_gemm_profile_read(wfl_model* m, int32_t max_variants, int32_t* keys, int64_t* launches, double* total_ms,
                               double* total_flops, int32_t* n_variants, int32_t reset);
+
+/* ---- host-side label logic (no device access): thresholded ids + offsets of one clip -> segments -> .lab text.
+ * Replaces the per-frame Python of /root/reference/utils.py:10-81, 148-186 and the scipy median filter call at
+ * /root/reference/infer.py:170-171, 298-299; bit-exact with them (times are doubles computed in the same order).
+ *   kind[c] : 0 the "O" tag, 1 "B-x", 2 "I-x", 3 anything else (ignored);  phon[c] : phoneme index of tag c (-1 for "O")
+ *   merge mode : 0 none, 1 right, 2 left, 3 previous (config postprocess.merge_segments)
+ * wfl_host_decode_bio returns the number of segments (-3 when max_segments was too small, -4 when a run closes at a frame
+ * beyond the n_off offsets rows, where the reference raises IndexError), wfl_host_merge_segments the
+ * new count (in place), wfl_host_format_lab the number of bytes the text needs (written only if it fits in cap). */
+int32_t wfl_host_median_filter(const int32_t* ids, int32_t n, int32_t size, int32_t* out);
+int32_t wfl_host_decode_bio(const int32_t* ids, int32_t T, const float* offsets, int32_t n_off, const int32_t* kind,
+                            const int32_t* phon, int32_t n_labels, double frame_duration, double* seg_start,
+                            double* seg_end, int32_t* seg_ph, int32_t max_segments);
+int32_t wfl_host_merge_segments(double* start, double* end, int32_t* ph, int32_t n, int32_t mode);
+int64_t wfl_host_format_lab(const double* start, const double* end, const int32_t* ph, int32_t n,
+                            const char* const* names, int32_t n_names, char* out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -58,7 +58,13 @@ def _manual(lab, path, lang_id, thr):
     for c, r in zip(chunks, raw):
         x = torch.from_numpy(np.ascontiguousarray(c))[None].cuda()
         res = lab.model.label(x, None if lang_id is None else [lang_id], threshold=thr, average_languages=lang_id is None)
-        segs = lab._segments_of_item(res.ids[0].cpu().numpy(), res.offsets[0].cpu().numpy(), lang_name)
+        # the reference's own host logic (postprocess.py, pinned to the reference by fixtures) -- the product path runs the
+        # native implementation (csrc/hostpost.hip), so this also holds the two against each other end to end
+        ids = pp.median_filter_ids(res.ids[0].cpu().numpy(), int(lab.config["postprocess"]["median_filter"]))
+        tags = [lab.model.id2label[int(i)] for i in ids]
+        segs = pp.decode_bio_tags(tags, offsets=res.offsets[0].cpu().numpy())
+        if lab.merge_map and lang_name:
+            segs = [(s, e, pp.canonical_to_lang(ph, lang_name, lab.merge_map)) for s, e, ph in segs]
         out.extend((s + clock, e + clock, ph) for s, e, ph in segs)
         clock += len(r) / 16000
     return pp.merge_adjacent_segments(out, "right")

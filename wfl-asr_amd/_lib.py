@@ -49,6 +49,10 @@ SIGNATURES = {
     "wfl_op_attention": (_I, [_P, _L, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
     "wfl_op_layernorm": (_I, [_P, _L, _P, _L, _P, _P, _F, _L, _I, _I, _I, _I, _P]),
     "wfl_op_tag_decide": (_I, [_P, _L, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "wfl_host_median_filter": (_I, [_P, _I, _I, _P]),
+    "wfl_host_decode_bio": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_double, _P, _P, _P, _I]),
+    "wfl_host_merge_segments": (_I, [_P, _P, _P, _I, _I]),
+    "wfl_host_format_lab": (_L, [_P, _P, _P, _I, _P, _I, _P, _L]),
     "wfl_gemm_profile_enable": (_I, [_P, _I]),
     "wfl_gemm_profile_read": (_I, [_P, _I, _P, _P, _P, _P, _P, _I]),
 }

@@ -22,6 +22,7 @@ import torch
 import yaml
 
 from . import audio as A
+from . import native_post as npost
 from . import postprocess as pp
 from .tagger import BIOPhonemeTagger
 
@@ -65,6 +66,8 @@ class Labeler:
         self.batch_size = int(batch_size)
         self.use_graph = bool(use_graph)
         self._pinned = None
+        self._table = npost.LabelTable(self.labels)          # native BIO decode works on ids (csrc/hostpost.hip)
+        self._streams = None
 
     # ------------------------------------------------------------------ the batched loop
     def _forward_items(self, items, lang_id, threshold):
@@ -74,23 +77,51 @@ class Labeler:
         out = [None] * len(items)
         Bs = self.batch_size
         L = CHUNK_SAMPLES
+        T = self.model.num_frames(L)
+        # Two batches in flight: while the GPU labels batch k on stream k % 2 (own workspace slot, own pinned input and
+        # output buffers), the host fills batch k + 1 and unpacks batch k - 1.
         if self._pinned is None:
-            self._pinned = torch.zeros(Bs, L, dtype=torch.float32).pin_memory()
-        for s in range(0, len(items), Bs):
+            self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._pinned_out = [torch.empty(Bs * T * 4, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
+        use_pipe = not self.use_graph
+        pending = [None, None]
+
+        def finish(slot):
+            job = pending[slot]
+            if job is None:
+                return
+            s0, n, ev = job
+            ev.synchronize()
+            blob = self._pinned_out[slot].numpy()
+            nn = Bs * T
+            ids = blob[0:nn].reshape(Bs, T)
+            offs = blob[2 * nn:4 * nn].view(np.float32).reshape(Bs, T, 2)
+            for i in range(n):
+                out[s0 + i] = (ids[i].copy(), offs[i].copy())
+            pending[slot] = None
+
+        for k, s in enumerate(range(0, len(items), Bs)):
+            slot = k % 2 if use_pipe else 0
+            finish(slot)                                   # the buffers of this slot are free again
             chunk = items[s:s + Bs]
-            host = self._pinned
+            host = self._pinned[slot]
             lens = np.zeros(Bs, dtype=np.int32)
             for i, x in enumerate(chunk):
                 n = min(len(x), L)
                 host[i, :n] = torch.from_numpy(np.ascontiguousarray(x[:n]))
                 lens[i] = n
-            dev_wav = host.to(self.device, non_blocking=True)
-            res = self.model.label(dev_wav, None if lang_id is None else [lang_id] * Bs, threshold=threshold, lens=lens,
-                                   average_languages=lang_id is None, graph=self.use_graph)
-            ids = res.ids.cpu().numpy()
-            offs = res.offsets.cpu().numpy()
-            for i in range(len(chunk)):
-                out[s + i] = (ids[i], offs[i])
+            stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(stream):
+                dev_wav = host.to(self.device, non_blocking=True)
+                res = self.model.label(dev_wav, None if lang_id is None else [lang_id] * Bs, threshold=threshold, lens=lens,
+                                       average_languages=lang_id is None, graph=self.use_graph, slot=slot)
+                self._pinned_out[slot].copy_(res.packed, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            pending[slot] = (s, len(chunk), ev)
+        finish(0)
+        finish(1)
         return out
 
     def _forward_items_by_length(self, items, lang_id, threshold):
@@ -118,16 +149,33 @@ class Labeler:
                 return n
         return None
 
+    def _names_for(self, lang_name):
+        """phoneme index -> (index into unique output names, names): the merge-map back-mapping (utils.py:206-211) applied to
+        the phoneme table once instead of to every segment; phonemes that map to the same string share an index, so the
+        equal-neighbour merge compares exactly what the reference's string comparison compares."""
+        key = lang_name if (self.merge_map and lang_name) else None
+        cache = getattr(self, "_names_cache", None)
+        if cache is None:
+            cache = self._names_cache = {}
+        if key not in cache:
+            mapped = [pp.canonical_to_lang(ph, key, self.merge_map) if key else ph for ph in self._table.names]
+            uniq, remap = [], np.empty(max(len(mapped), 1), np.int32)
+            index = {}
+            for i, nm in enumerate(mapped):
+                if nm not in index:
+                    index[nm] = len(uniq)
+                    uniq.append(nm)
+                remap[i] = index[nm]
+            cache[key] = (remap, uniq)
+        return cache[key]
+
     def _segments_of_item(self, ids, offsets, lang_name):
-        """suppressed ids -> median filter -> BIO decode -> merge-map back-mapping (infer.py:164-179, 293-307)."""
+        """suppressed ids -> median filter -> BIO decode -> merge-map back-mapping (infer.py:164-179, 293-307), in native
+        code; returns (start[n] f64, end[n] f64, name index[n]) arrays."""
         mf = int(self.config["postprocess"]["median_filter"])
-        if mf > 1:
-            ids = pp.median_filter_ids(ids, mf)
-        tags = [self.model.id2label[int(i)] for i in ids]
-        segs = pp.decode_bio_tags(tags, frame_duration=frame_duration, offsets=offsets)
-        if self.merge_map and lang_name:
-            segs = [(s, e, pp.canonical_to_lang(ph, lang_name, self.merge_map)) for s, e, ph in segs]
-        return segs
+        s, e, ph = npost.decode_bio_ids(ids, self._table, frame_duration, offsets, median=mf)
+        remap, _ = self._names_for(lang_name)
+        return s, e, remap[ph] if ph.size else ph
 
     def label_files(self, audio_paths, lang_id=None, confidence_threshold=0.0, verbose=True):
         """-> list (per file) of [(start_s, end_s, phoneme)] after merge + forced alignment."""
@@ -151,16 +199,21 @@ class Labeler:
         results = [[] for _ in audio_paths]
         clock = [0.0] * len(audio_paths)
         for (ids, offs), fi, n in zip(decided, owner, chunk_lens):
-            segs = self._segments_of_item(ids, offs, lang_name)
+            s, e, ph = self._segments_of_item(ids, offs, lang_name)
             t0 = clock[fi]
-            results[fi].extend((s + t0, e + t0, ph) for s, e, ph in segs)
+            results[fi].append((s + t0, e + t0, ph))
             clock[fi] += n / self.sr
+        names = self._names_for(lang_name)[1]
         final = []
         for fi, path in enumerate(audio_paths):
-            segs = results[fi]
+            parts = results[fi]
+            s = np.concatenate([p[0] for p in parts]) if parts else np.empty(0)
+            e = np.concatenate([p[1] for p in parts]) if parts else np.empty(0)
+            ph = np.concatenate([p[2] for p in parts]).astype(np.int32) if parts else np.empty(0, np.int32)
             mode = self.config["postprocess"]["merge_segments"]
-            if mode != "none":
-                segs = pp.merge_adjacent_segments(segs, mode=mode)
+            if mode != "none" and s.size:
+                s, e, ph = npost.merge_segments(s, e, ph, mode)
+            segs = npost.to_tuples(s, e, ph, names)
             forced = _read_forced(path, verbose)
             if forced is not None:
                 aligned = pp.align_phoneme_list(segs, forced)
