@@ -173,6 +173,15 @@ int32_t wfl_host_merge_segments(double* start, double* end, int32_t* ph, int32_t
 int64_t wfl_host_format_lab(const double* start, const double* end, const int32_t* ph, int32_t n,
                             const char* const* names, int32_t n_names, char* out, int64_t cap);
 
+/* ---- audio ingest on the host (replaces soundfile.read + the float64 peak normalisation of /root/reference/infer.py:217-218,
+ * 234-235 for 16-bit/24-bit/32-bit/float WAV files with 1 or 2 channels): decode, mono mix, audio / (max|audio| + 1e-8) in
+ * float64, stored as float32 -- bit-identical to wfl-asr_amd/audio.py.  status: 0 ok, 1 unsupported encoding, 2 more than two
+ * channels, 3 longer than cap samples (n_samples = the length), 4 cannot open.  The sample rate is reported, not converted.
+ * wfl_host_load_wavs fills rows out + i * ld of a batch buffer with `threads` worker threads. */
+int32_t wfl_host_load_wav(const char* path, float* out, int64_t cap, int32_t* n_samples, int32_t* sample_rate);
+int32_t wfl_host_load_wavs(const char* const* paths, int32_t n, float* out, int64_t ld, int64_t cap, int32_t* n_samples,
+                           int32_t* sample_rates, int32_t* status, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

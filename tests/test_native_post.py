@@ -110,3 +110,65 @@ def test_golden_fixture_cases():
             assert N.to_tuples(ms, me, mp, table.names) == [tuple(x) for x in want], mode
         for k, want in c["median"].items():
             assert N.median_filter_ids(c["ids"], int(k)).tolist() == want
+
+
+# ---- native audio ingest (wfl_host_load_wav[s]) against audio.py's read_wav + peak_normalize
+
+def _write(path, fmt_tag, ch, sr, bits, payload, extensible=False):
+    import struct
+    if extensible:
+        fmt = struct.pack("<HHIIHH", 0xFFFE, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits) + struct.pack("<HHI", 22, bits, 0) + \
+            struct.pack("<H", fmt_tag) + bytes(14)
+    else:
+        fmt = struct.pack("<HHIIHH", fmt_tag, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 3) + b"abc" + bytes(1) + \
+        b"data" + struct.pack("<I", len(payload)) + payload
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+@pytest.mark.parametrize("kind", ["pcm16", "pcm16_stereo", "pcm24", "pcm32", "pcm8", "f32", "f64_ext", "pcm16_44k"])
+def test_native_wav_ingest_matches_python(kind, tmp_path):
+    from wfl_asr_amd import audio as A
+    rng = np.random.default_rng(len(kind))
+    n = 5000
+    x = rng.uniform(-0.7, 0.7, n)
+    path = str(tmp_path / f"{kind}.wav")
+    sr = 44100 if kind.endswith("44k") else 16000
+    if kind in ("pcm16", "pcm16_44k"):
+        _write(path, 1, 1, sr, 16, np.round(x * 32767).astype("<i2").tobytes())
+    elif kind == "pcm16_stereo":
+        y = rng.uniform(-0.5, 0.5, n)
+        _write(path, 1, 2, sr, 16, np.stack([np.round(x * 32767), np.round(y * 32767)], 1).astype("<i2").tobytes())
+    elif kind == "pcm24":
+        v = np.round(x * 8388607).astype(np.int32)
+        b = np.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], 1).astype(np.uint8)
+        _write(path, 1, 1, sr, 24, b.tobytes())
+    elif kind == "pcm32":
+        _write(path, 1, 1, sr, 32, np.round(x * 2147483647).astype("<i4").tobytes())
+    elif kind == "pcm8":
+        _write(path, 1, 1, sr, 8, np.round(x * 127 + 128).astype(np.uint8).tobytes())
+    elif kind == "f32":
+        _write(path, 3, 1, sr, 32, x.astype("<f4").tobytes())
+    elif kind == "f64_ext":
+        _write(path, 3, 1, sr, 64, x.astype("<f8").tobytes(), extensible=True)
+    want, want_sr = A.read_wav(path)
+    want = np.asarray(A.peak_normalize(want), np.float32)
+    rows = np.full((2, n + 7), 9.0, np.float32)
+    ns, srs, st = A.load_wavs_into([path, path], rows, n + 7, threads=2)
+    assert list(st) == [0, 0] and list(srs) == [want_sr, want_sr] and list(ns) == [want.size] * 2
+    assert np.array_equal(rows[0, :want.size], want) and np.array_equal(rows[1, :want.size], want)
+    assert (rows[:, want.size:] == 9.0).all()                    # nothing written past the clip
+
+
+def test_native_wav_ingest_status_codes(tmp_path):
+    from wfl_asr_amd import audio as A
+    x = np.zeros(100, "<i2")
+    p3 = str(tmp_path / "three.wav"); _write(p3, 1, 3, 16000, 16, np.zeros(300, "<i2").tobytes())
+    plong = str(tmp_path / "long.wav"); _write(plong, 1, 1, 16000, 16, np.zeros(500, "<i2").tobytes())
+    pbad = str(tmp_path / "bad.wav"); open(pbad, "wb").write(b"not a wav file at all")
+    pmu = str(tmp_path / "mulaw.wav"); _write(pmu, 7, 1, 16000, 8, bytes(100))
+    rows = np.zeros((5, 128), np.float32)
+    ns, srs, st = A.load_wavs_into([p3, plong, pbad, pmu, str(tmp_path / "missing.wav")], rows, 128, threads=3)
+    assert list(st) == [2, 3, 1, 1, 4] and ns[1] == 500
+    assert (rows == 0).all()

@@ -53,6 +53,8 @@ SIGNATURES = {
     "wfl_host_decode_bio": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_double, _P, _P, _P, _I]),
     "wfl_host_merge_segments": (_I, [_P, _P, _P, _I, _I]),
     "wfl_host_format_lab": (_L, [_P, _P, _P, _I, _P, _I, _P, _L]),
+    "wfl_host_load_wav": (_I, [C.c_char_p, _P, _L, _P, _P]),
+    "wfl_host_load_wavs": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _I]),
     "wfl_gemm_profile_enable": (_I, [_P, _I]),
     "wfl_gemm_profile_read": (_I, [_P, _I, _P, _P, _P, _P, _P, _I]),
 }

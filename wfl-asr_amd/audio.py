@@ -14,6 +14,7 @@ image, so decode and resampling are restated here:
 from __future__ import annotations
 
 import math
+import os
 import struct
 
 import numpy as np
@@ -122,6 +123,32 @@ def load_clip(path: str, sample_rate: int = 16000):
     if sr != sample_rate:
         x = resample(x, sr, sample_rate)
     return peak_normalize(x)
+
+
+def load_wavs_into(paths, rows, cap: int, threads: int = 8):
+    """Native, threaded fast path of `load_clip` + float32 cast for a batch of files (csrc/hostpost.hip through the C ABI):
+    file i is decoded, mixed to mono, peak-normalised in float64 and stored as float32 into rows[i, :n] (a torch / numpy
+    float32 [B, ld] buffer, normally pinned memory).  -> (n_samples, sample_rates, status) int32 arrays; status 0 = done,
+    anything else = the caller must take the Python path for that file (see include/wfl_asr.h).  Bit-identical to
+    `np.asarray(load_clip(path), np.float32)` for the files it accepts."""
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    n = len(paths)
+    enc = [os.fsencode(p) for p in paths]
+    arr = (C.c_char_p * max(n, 1))(*enc)
+    ns = np.zeros(max(n, 1), np.int32)
+    srs = np.zeros(max(n, 1), np.int32)
+    st = np.zeros(max(n, 1), np.int32)
+    if hasattr(rows, "data_ptr"):
+        ptr, ld = rows.data_ptr(), rows.stride(0)
+    else:
+        ptr, ld = rows.ctypes.data, rows.strides[0] // 4
+    rc = lib.wfl_host_load_wavs(arr, n, C.c_void_p(ptr), ld, int(cap), ns.ctypes.data_as(C.c_void_p),
+                                srs.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), int(threads))
+    _lib.check(rc, "wfl_host_load_wavs")
+    return ns[:n], srs[:n], st[:n]
 
 
 def chunk_clip(audio: np.ndarray, sr: int = 16000):

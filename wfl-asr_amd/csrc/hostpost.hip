@@ -161,3 +161,125 @@ int64_t wfl_host_format_lab(const double* start, const double* end, const int32_
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ audio ingest
+// WAV decode + mono mix + peak normalisation of one clip straight into a caller buffer (normally a row of the pinned batch
+// that is DMA'd to the GPU), and a threaded loop over a batch of files.  Restates wfl-asr_amd/audio.py's read_wav +
+// peak_normalize (/root/reference/infer.py:217-218, 234-235: soundfile.read -> float64, audio / (max|audio| + 1e-8) in
+// float64, then float32) operation for operation, so the samples are bit-identical to the Python path; anything the fast
+// path does not cover (other sample rates, > 2 channels, clips longer than the row) is reported by status code and goes
+// through the Python path.
+#include <thread>
+#include <atomic>
+#include <cmath>
+
+namespace {
+
+struct WavInfo { int tag = 0, ch = 0, sr = 0, bits = 0; const unsigned char* pcm = nullptr; size_t pcm_bytes = 0; };
+
+bool parse_wav(const std::vector<unsigned char>& d, WavInfo& w) {
+  if (d.size() < 12 || memcmp(d.data(), "RIFF", 4) || memcmp(d.data() + 8, "WAVE", 4)) return false;
+  size_t pos = 12;
+  bool have_fmt = false, have_data = false;
+  auto u16 = [&](size_t o) { return (unsigned)d[o] | ((unsigned)d[o + 1] << 8); };
+  auto u32 = [&](size_t o) { return (unsigned)d[o] | ((unsigned)d[o + 1] << 8) | ((unsigned)d[o + 2] << 16) | ((unsigned)d[o + 3] << 24); };
+  while (pos + 8 <= d.size()) {
+    const size_t size = u32(pos + 4);
+    const size_t body = pos + 8;
+    const size_t avail = body <= d.size() ? std::min(size, d.size() - body) : 0;
+    if (!memcmp(d.data() + pos, "fmt ", 4) && avail >= 16) {
+      w.tag = (int)u16(body); w.ch = (int)u16(body + 2); w.sr = (int)u32(body + 4); w.bits = (int)u16(body + 14);
+      if (w.tag == 0xFFFE && avail >= 26) w.tag = (int)u16(body + 24);
+      have_fmt = true;
+    } else if (!memcmp(d.data() + pos, "data", 4)) {
+      w.pcm = d.data() + body; w.pcm_bytes = avail;          // (a later data chunk replaces an earlier one, like the Python loop)
+      have_data = true;
+    }
+    pos += 8 + size + (size & 1);
+  }
+  return have_fmt && have_data;
+}
+
+// status: 0 ok; 1 not a WAV / unsupported encoding; 2 more than 2 channels; 3 longer than cap; 4 cannot open
+int load_one(const char* path, float* out, long cap, int32_t* n_out, int32_t* sr_out) {
+  *n_out = 0; *sr_out = 0;
+  FILE* f = fopen(path, "rb");
+  if (!f) return 4;
+  std::vector<unsigned char> d;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (sz > 0) { d.resize((size_t)sz); if (fread(d.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return 4; } }
+  fclose(f);
+  WavInfo w;
+  if (!parse_wav(d, w)) return 1;
+  *sr_out = w.sr;
+  const int bps = w.bits / 8;
+  if (!((w.tag == 1 && (w.bits == 8 || w.bits == 16 || w.bits == 24 || w.bits == 32)) || (w.tag == 3 && (w.bits == 32 || w.bits == 64)))) return 1;
+  if (w.ch < 1) return 1;
+  if (w.ch > 2) return 2;
+  const size_t total = w.pcm_bytes / (size_t)bps;             // scalar samples
+  const size_t frames = total / (size_t)w.ch;
+  if ((long)frames > cap) { *n_out = (int32_t)std::min<size_t>(frames, 0x7fffffff); return 3; }
+  auto sample = [&](size_t i) -> double {
+    const unsigned char* p = w.pcm + i * (size_t)bps;
+    if (w.tag == 1) {
+      if (w.bits == 8) return ((double)p[0] - 128.0) / 128.0;
+      if (w.bits == 16) { const int16_t v = (int16_t)((unsigned)p[0] | ((unsigned)p[1] << 8)); return (double)v / 32768.0; }
+      if (w.bits == 24) { int32_t v = (int32_t)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16)); if (v & 0x800000) v -= 0x1000000; return (double)v / 8388608.0; }
+      const int32_t v = (int32_t)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+      return (double)v / 2147483648.0;
+    }
+    if (w.bits == 32) { float v; memcpy(&v, p, 4); return (double)v; }
+    double v; memcpy(&v, p, 8); return v;
+  };
+  // pass 1: peak of |mono|;  mono of 2 channels = (a + b) / 2, numpy's mean over a length-2 axis
+  double peak = 0.0;
+  bool nan_seen = false;
+  for (size_t i = 0; i < frames; ++i) {
+    const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
+    const double a = std::fabs(x);
+    if (a != a) nan_seen = true;
+    if (a > peak) peak = a;
+  }
+  if (nan_seen) return 1;                                      // numpy's max would propagate the NaN: leave it to the Python path
+  const double den = peak + 1e-8;
+  for (size_t i = 0; i < frames; ++i) {
+    const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
+    out[i] = (float)(x / den);
+  }
+  *n_out = (int32_t)frames;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t wfl_host_load_wav(const char* path, float* out, int64_t cap, int32_t* n_samples, int32_t* sample_rate) {
+  if (!path || !out || !n_samples || !sample_rate || cap < 0) return -1;
+  return load_one(path, out, (long)cap, n_samples, sample_rate);
+}
+
+// rows: out + i * ld floats, each with room for `cap` samples; files are dealt to `threads` workers dynamically.
+int32_t wfl_host_load_wavs(const char* const* paths, int32_t n, float* out, int64_t ld, int64_t cap, int32_t* n_samples,
+                           int32_t* sample_rates, int32_t* status, int32_t threads) {
+  if (n < 0 || (n && (!paths || !out || !n_samples || !sample_rates || !status)) || cap > ld) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n > 0 ? n : 1;
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      status[i] = load_one(paths[i], out + (size_t)i * (size_t)ld, (long)cap, n_samples + i, sample_rates + i);
+    }
+  };
+  if (threads == 1) { work(); return 0; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+  for (auto& t : pool) t.join();
+  return 0;
+}
+
+}  // extern "C"

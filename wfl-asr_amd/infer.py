@@ -77,9 +77,30 @@ class Labeler:
         out = [None] * len(items)
         Bs = self.batch_size
         L = CHUNK_SAMPLES
+
+        def fill(k, host):
+            chunk = items[k * Bs:(k + 1) * Bs]
+            lens = np.zeros(Bs, dtype=np.int32)
+            for i, x in enumerate(chunk):
+                n = min(len(x), L)
+                host[i, :n] = torch.from_numpy(np.ascontiguousarray(x[:n]))
+                lens[i] = n
+            return lens, len(chunk)
+
+        def take(k, n, ids, offs):
+            for i in range(n):
+                out[k * Bs + i] = (ids[i].copy(), offs[i].copy())
+
+        self._run_batches((len(items) + Bs - 1) // Bs, fill, take, lang_id, threshold)
+        return out
+
+    def _run_batches(self, n_batches, fill, take, lang_id, threshold):
+        """The pipelined hot loop.  Two batches in flight: while the GPU labels batch k on stream k % 2 (own workspace slot,
+        own pinned input and output buffers), the host fills batch k + 1 (`fill(k, pinned_rows) -> (lens, rows used)`) and
+        unpacks batch k - 1 (`take(k, rows, ids[B, T], offsets[B, T, 2])`, views into pinned memory: copy what you keep)."""
+        Bs = self.batch_size
+        L = CHUNK_SAMPLES
         T = self.model.num_frames(L)
-        # Two batches in flight: while the GPU labels batch k on stream k % 2 (own workspace slot, own pinned input and
-        # output buffers), the host fills batch k + 1 and unpacks batch k - 1.
         if self._pinned is None:
             self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(2)]
             self._pinned_out = [torch.empty(Bs * T * 4, dtype=torch.int32).pin_memory() for _ in range(2)]
@@ -91,26 +112,18 @@ class Labeler:
             job = pending[slot]
             if job is None:
                 return
-            s0, n, ev = job
+            k, n, ev = job
             ev.synchronize()
             blob = self._pinned_out[slot].numpy()
             nn = Bs * T
-            ids = blob[0:nn].reshape(Bs, T)
-            offs = blob[2 * nn:4 * nn].view(np.float32).reshape(Bs, T, 2)
-            for i in range(n):
-                out[s0 + i] = (ids[i].copy(), offs[i].copy())
+            take(k, n, blob[0:nn].reshape(Bs, T), blob[2 * nn:4 * nn].view(np.float32).reshape(Bs, T, 2))
             pending[slot] = None
 
-        for k, s in enumerate(range(0, len(items), Bs)):
+        for k in range(n_batches):
             slot = k % 2 if use_pipe else 0
             finish(slot)                                   # the buffers of this slot are free again
-            chunk = items[s:s + Bs]
             host = self._pinned[slot]
-            lens = np.zeros(Bs, dtype=np.int32)
-            for i, x in enumerate(chunk):
-                n = min(len(x), L)
-                host[i, :n] = torch.from_numpy(np.ascontiguousarray(x[:n]))
-                lens[i] = n
+            lens, n = fill(k, host)
             stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
             with torch.cuda.stream(stream):
                 dev_wav = host.to(self.device, non_blocking=True)
@@ -119,10 +132,9 @@ class Labeler:
                 self._pinned_out[slot].copy_(res.packed, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
-            pending[slot] = (s, len(chunk), ev)
+            pending[slot] = (k, n, ev)
         finish(0)
         finish(1)
-        return out
 
     def _forward_items_by_length(self, items, lang_id, threshold):
         """WavLM: the frame count follows the clip length, so rows are grouped by exact length."""
@@ -177,15 +189,48 @@ class Labeler:
         remap, _ = self._names_for(lang_name)
         return s, e, remap[ph] if ph.size else ph
 
+    def _label_fast(self, audio_paths, lang_id, threshold):
+        """Files the native loader takes whole (16 kHz, <= 30 s, <= 2 channels, PCM / float WAV): decoded, normalised and
+        converted by worker threads straight into the pinned batch rows (audio.load_wavs_into), one file per row.  Returns
+        {file index: (ids, offsets, samples)}; every other file is left to the general path."""
+        Bs, L = self.batch_size, CHUNK_SAMPLES
+        done = {}
+        meta = {}
+        threads = max(1, min(16, (os.cpu_count() or 1)))
+
+        def fill(k, host):
+            sel = list(range(k * Bs, min((k + 1) * Bs, len(audio_paths))))
+            ns, srs, st = A.load_wavs_into([audio_paths[i] for i in sel], host, L, threads)
+            lens = np.zeros(Bs, dtype=np.int32)
+            ok = []
+            for r, fi in enumerate(sel):
+                if st[r] == 0 and srs[r] == self.sr and ns[r] > 0:
+                    lens[r] = ns[r]
+                    ok.append((r, fi, int(ns[r])))
+            meta[k] = ok
+            return lens, len(sel)
+
+        def take(k, n, ids, offs):
+            for r, fi, ns in meta.pop(k):
+                done[fi] = (ids[r].copy(), offs[r].copy(), ns)
+
+        self._run_batches((len(audio_paths) + Bs - 1) // Bs, fill, take, lang_id, threshold)
+        return done
+
     def label_files(self, audio_paths, lang_id=None, confidence_threshold=0.0, verbose=True):
         """-> list (per file) of [(start_s, end_s, phoneme)] after merge + forced alignment."""
         if lang_id is not None and self.lang2id and lang_id > max(self.lang2id.values()):
             raise ValueError(f"Error: Language ID ({lang_id}) is higher than the latest ID ({max(self.lang2id.values())}) "
                              f"of this model.\n Languages and Codes available: {self.lang2id}")
         lang_name = self._lang_name(lang_id)
+        decided_fast = {}                                 # file index -> (ids, offsets, samples): one <= 30 s item, natively loaded
+        if self.model.encoder_type == "whisper" and len(audio_paths) > 0:
+            decided_fast = self._label_fast(audio_paths, lang_id, confidence_threshold)
         items, owner = [], []
         chunk_lens = []
         for fi, path in enumerate(audio_paths):
+            if fi in decided_fast:
+                continue
             audio = A.load_clip(path, self.sr)
             if verbose and len(audio) / self.sr > MAX_SEGMENT_DURATION:
                 print(f"Audio is too long ({len(audio)/self.sr:.1f}s), splitting...")
@@ -195,7 +240,11 @@ class Labeler:
                 items.append(c)
                 owner.append(fi)
                 chunk_lens.append(n)
-        decided = self._forward_items(items, lang_id, confidence_threshold)
+        decided = self._forward_items(items, lang_id, confidence_threshold) if items else []
+        for fi, (ids, offs, n) in decided_fast.items():
+            decided.append((ids, offs))
+            owner.append(fi)
+            chunk_lens.append(n)
         results = [[] for _ in audio_paths]
         clock = [0.0] * len(audio_paths)
         for (ids, offs), fi, n in zip(decided, owner, chunk_lens):
