@@ -226,8 +226,9 @@ def main():
                 act, glu, f32, res, kid = key & 3, bool(key & 4), bool(key & 8), bool(key & 16), (key >> 5) & 7
                 lnf, stats = (key >> 8) & 3, bool(key & 1024)
                 tf = lambda b: "true" if b else "false"
-                if kid in (1, 5):
-                    return "gemm_stream_kernel<%d, %d, %s, %d, %s>" % (acts[act], 6 if kid == 1 else 8, tf(res), lnf, tf(stats))
+                if kid in (1, 5, 6):                  # 6 = the tap-stationary conv mode
+                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
+                                                                           tf(kid == 6))
                 if kid in (2, 3):
                     return "gemm256_kernel<%d, %s, %s, %d, false>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
                 return "gemm_bf16_kernel<%d, %s, %s, false>" % (acts[act], tf(glu), tf(f32))

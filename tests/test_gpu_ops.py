@@ -357,3 +357,23 @@ def test_gemm_stream_layernorm_fold(B, T, K, N, act):
     y = [y, F.gelu(y)][act]
     _close(out.get(), y, rtol=2e-2, atol=2e-2, what="LN-folded gemm")
     assert out.halo_is_zero()
+
+
+@pytest.mark.parametrize("C,k,N,act", [(256, 31, 256, 1), (512, 31, 512, 1), (128, 3, 256, 0), (64, 5, 256, 2), (192, 4, 256, 1)])
+def test_gemm_stream_dense_conv_tap_stationary(C, k, N, act):
+    """dense k-tap Conv1d given as (cin = C, tap stride = one row): the streaming kernel's tap-stationary mode (the frame tile of
+    a channel chunk is staged once and re-read at a row offset per tap); odd chunk counts, both few and many taps."""
+    B, T = 3, 700
+    x0 = _rand(B, T, C, seed=81)
+    a = G.Rows(B, T, C, halo=32, lead=32).set(x0)
+    w, bias = _rand(N, C, k, scale=(k * C) ** -0.5, seed=82), _rand(N, scale=0.1, seed=83)
+    wp, bp = G.pad_weight(w.permute(0, 2, 1).reshape(N, k * C), bias)
+    assert wp.shape[1] == k * C
+    out = G.Rows(B, T, N, halo=32, lead=32)
+    left = (k - 1) // 2                                           # (even k: one more tap to the right)
+    G.gemm(a.buf, (a.lead - left) * C, C, wp, B * a.P, N, a.P, T, out.buf, N, out.lead, out.P, bias=bp, act=act, cin=C, tap_stride=C)
+    torch.cuda.synchronize()
+    ref = F.conv1d(F.pad(_bf(x0).transpose(1, 2), (left, k - 1 - left)), _bf(w), bias).transpose(1, 2)
+    ref = [ref, F.gelu(ref), F.relu(ref)][act]
+    _close(out.get(), ref, what="tap-stationary conv")
+    assert out.halo_is_zero()

@@ -85,7 +85,7 @@ def main():
         ln_s = W.float().sum(1).contiguous()
 
         def run(lib, with_stamps):
-            return lib.diag_gemm(C.c_void_p(A.data_ptr() + aoff), lda, 0, 0, C.c_void_p(W.data_ptr()), M, N, K, P, T,
+            return lib.diag_gemm(C.c_void_p(A.data_ptr() + aoff), lda, 512 if K > 2048 else 0, 512 if K > 2048 else 0, C.c_void_p(W.data_ptr()), M, N, K, P, T,
                                  C.c_void_p(Cb.data_ptr()), N, lead, C.c_void_p(bias.data_ptr()),
                                  C.c_void_p(Rs.data_ptr()) if res else None, act,
                                  C.c_void_p(stamps.data_ptr()) if with_stamps else None,

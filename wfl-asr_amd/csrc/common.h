@@ -108,7 +108,7 @@ static __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
 // host-side launchers (one per .hip translation unit)
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s);
-// which kernel the last wfl_launch_gemm used (profiling labels): 1 gemm_stream<.,6>, 2 gemm256<.,6>, 3 gemm256<.,8>, 4 gemm_bf16 (128 tile), 5 gemm_stream<.,8>
+// which kernel the last wfl_launch_gemm used (profiling labels): 1 gemm_stream<.,6>, 2 gemm256<.,6>, 3 gemm256<.,8>, 4 gemm_bf16 (128 tile), 5 gemm_stream<.,8>, 6 gemm_stream conv mode
 extern int g_wfl_gemm_kernel_id;
 bool wfl_gemm_stream_takes(const GemmArgs& a);   // gemm_stream.hip: would the streaming (LayerNorm-folding) kernel take it
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s);

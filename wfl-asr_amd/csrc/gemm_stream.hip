@@ -38,6 +38,10 @@ static __device__ __forceinline__ void sglds(const bf16_t* g, char* l) {
   __builtin_amdgcn_global_load_lds((sgptr_t)g, (slptr_t)l, 16, 0, 0);
 }
 static __device__ __forceinline__ int sswz(int row) { return (-(row >> 2)) & 3; }
+// Swizzle of the CONV extended frame tile: its fragment reads start at ANY row (one per tap), and 2 * ((row >> 2) & 1) is one of
+// the eight 16-byte-chunk XORs that keep 16 consecutive rows from any start conflict-free for ds_read_b128 (exhaustive search
+// over the functions of (row >> 2) & 3; the aligned-only sswz above costs 2-way conflicts on 3 taps of 4: +0.10 us per K step).
+static __device__ __forceinline__ int xswz(int row) { return ((row >> 2) & 1) << 1; }
 template <int N>
 static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -49,20 +53,27 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 
 // LNF: 0 no LayerNorm, 1 folded with statistics summed in the kernel, 2 folded with statistics read from p.stats_in.
 // STATS: the (residual) epilogue also writes p.stats_out for the next LayerNorm-folded consumer.
-template <int ACT, int MT, bool RES, int LNF, bool STATS>
+// CONV: dense multi-tap Conv1d (taps one input row apart, K = taps x cin): K is walked channel-chunk-major / tap-minor and the
+//   frame operand of a whole chunk -- the tile's 192 rows plus the taps - 1 rows of overlap, 32 channels -- is staged ONCE and
+//   re-read at a one-row offset per tap, so a K step moves 16 KiB (the weight tile) instead of 28: the k = 31 Conformer conv
+//   (a quarter of the model's FLOPs) leaves the L2 -> LDS bound and becomes MFMA-bound.
+template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
+  static_assert(!CONV || (MT == 6 && !RES && LNF == 0 && !STATS), "conv mode: 192-row tiles, plain epilogue");
   constexpr int BMV = MT * 32;                    // frame rows per tile
 #ifdef WFL_LAB_STB32
   constexpr int STB = 512 * SBK * 2;
   constexpr int WOFF = 256 * SBK * 2;
 #else
-  constexpr int STB = (BMV + 256) * SBK * 2;      // stage bytes: frame tile then weight tile
-  constexpr int WOFF = BMV * SBK * 2;
+  constexpr int STB = CONV ? 256 * SBK * 2 : (BMV + 256) * SBK * 2;      // stage bytes: frame tile then weight tile
+  constexpr int WOFF = CONV ? 0 : BMV * SBK * 2;
 #endif
+  constexpr int AEXT = 224 * SBK * 2;             // CONV: extended frame tile (BMV + up to 32 taps - 1 rows), two of them
+  constexpr int AOFF = SNST * STB;
   constexpr int NSTORE = 2 * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around)
   constexpr int SROW = 4;                             // float2 slots per row of the statistics buffer (one per 256-column tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* stat_lds = (float*)(smem + SNST * STB);  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
+  float* stat_lds = (float*)(smem + SNST * STB + (CONV ? 2 * AEXT : 0));  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,13 +96,16 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   const int wm = grp * (MT * 16), wn = wq * 64;
 
   // ---- operand stream (prefetch cursor).  Frame row groups: MT = 8: waves load two each; MT = 6: waves 0-3 two, 4-7 one.
-  const bool two_x = MT == 8 || wid < 4;
-  const int xg0 = (MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4);
+  // (CONV: the 14 row groups of the extended tile: waves 0-5 two each, 6-7 one)
+  const bool two_x = CONV ? wid < 6 : (MT == 8 || wid < 4);
+  const int xg0 = CONV ? (wid < 6 ? wid * 2 : 12 + (wid - 6)) : ((MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4));
+  const int ntaps = CONV ? p.K / p.cin : 1;
   const bf16_t* a_src[2];
   const bf16_t* w_src[2];
   int pv = blockIdx.x, pkt = 0, issued = 0;
   int ptap_k = 0;                                   // position inside the current tap (conv GEMMs), elements
   long pbase = 0;                                   // tap * tap_stride
+  int pcc = 0, ptap = 0, pccg = 0;                  // CONV: channel chunk / tap being issued; chunks issued so far (buffer parity)
   auto set_src = [&](int v) __attribute__((always_inline)) {
     int m0, n0;
     tile_of(v, m0, n0);
@@ -100,13 +114,28 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       const int wrow = (wid * 2 + i) * 16 + (lane >> 2);
       const int xrow = (xg0 + i) * 16 + (lane >> 2);
       int am = m0 + xrow;
-      am = am < p.M ? am : p.M - 1;
-      a_src[i] = p.A + (long)am * p.lda + ((lane & 3) ^ sswz(xrow)) * 8;
+      const int am_max = CONV ? p.M - 1 + ntaps - 1 : p.M - 1;     // (conv: row m + tap of the caller's buffer, as in gemm.hip)
+      am = am < am_max ? am : am_max;
+      a_src[i] = p.A + (long)am * p.lda + ((lane & 3) ^ (CONV ? xswz(xrow) : sswz(xrow))) * 8;
       w_src[i] = p.W + (long)(n0 + wrow) * p.K + ((lane & 3) ^ sswz(wrow)) * 8;
     }
   };
   set_src(pv);
   auto issue_stage = [&]() __attribute__((always_inline)) {                        // the DMA of stage (pv, pkt); advances the position inside the tile
+    if (CONV) {
+      char* base = smem + (issued & (SNST - 1)) * STB;
+      if (ptap == 0) {                               // first tap of a channel chunk: its extended frame tile rides along
+        char* ab = smem + AOFF + (pccg & 1) * AEXT;
+        sglds(a_src[0] + pcc * SBK, ab + xg0 * 1024);
+        if (two_x) sglds(a_src[1] + pcc * SBK, ab + xg0 * 1024 + 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sglds(w_src[i] + ptap * p.cin + pcc * SBK, base + wid * 2048 + i * 1024);
+      ++issued;
+      ++pkt;
+      if (++ptap == ntaps) { ptap = 0; ++pcc; ++pccg; }
+      return;
+    }
     const long koff = pbase + ptap_k;
     char* base = smem + (issued & (SNST - 1)) * STB;
     sglds(a_src[0] + koff, base + xg0 * 1024);
@@ -122,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     if (pv >= ntiles) return;
     issue_stage();
     if (pkt == nk) {
-      pkt = 0; ptap_k = 0; pbase = 0;
+      pkt = 0; ptap_k = 0; pbase = 0; pcc = 0; ptap = 0;
       pv += G;
       if (pv < ntiles) set_src(pv);
     }
@@ -132,6 +161,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   auto wait_stage = [&](int need, bool with_stores) __attribute__((always_inline)) {
     const int younger = issued - need - 1;
     if (younger < 0) return;                        // no such stage (end of the stream)
+    if (CONV) {
+      // two weight-tile DMAs per wave and stage; the extended frame tile's DMAs (one stage in `taps`) are not counted: a
+      // smaller count only waits for more, and they are issued taps - 3 steps before their first read
+      if (younger >= 2) { if (with_stores) wait_vm<4 + NSTORE>(); else wait_vm<4>(); }
+      else if (younger == 1) { if (with_stores) wait_vm<2 + NSTORE>(); else wait_vm<2>(); }
+      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
+      return;
+    }
     if (two_x) {
       if (younger >= 2) { if (with_stores) wait_vm<8 + NSTORE>(); else wait_vm<8>(); }
       else if (younger == 1) { if (with_stores) wait_vm<4 + NSTORE>(); else wait_vm<4>(); }
@@ -306,10 +343,20 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #define SSB() __builtin_amdgcn_sched_barrier(0)
   bf16x8 fw[4], fx[MT];
   int s = 0;                                         // global K-step counter (ring slot = s & 3)
+  int ctap = 0, ccg = 0;                              // CONV: tap of the step being computed; chunks finished (buffer parity)
   auto read_frags = [&]() __attribute__((always_inline)) {
     const char* sb = smem + (s & (SNST - 1)) * STB;
 #pragma unroll
     for (int v = 0; v < 4; ++v) fw[v] = *(const bf16x8*)(sb + w_off[v]);
+    if (CONV) {
+      const char* ab = smem + AOFF + (ccg & 1) * AEXT;
+      const int r0 = wm + c + ctap;                  // row of the extended tile; + 16u never changes the swizzle
+      const int xb = r0 * 64 + ((g ^ xswz(r0)) << 4);
+#pragma unroll
+      for (int u = 0; u < MT; ++u) fx[u] = *(const bf16x8*)(ab + xb + u * 1024);
+      if (++ctap == ntaps) { ctap = 0; ++ccg; }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < MT; ++u) fx[u] = *(const bf16x8*)(sb + x_off + u * 1024);
   };
@@ -383,10 +430,16 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // nothing but operand DMA is in the queue, so the waits are constants.  One copy per wave group (no per-step branches).
     auto steps_steady = [&](auto grp_c) __attribute__((always_inline)) {
       constexpr bool GRP1 = decltype(grp_c)::value;
-      constexpr int NL = (MT == 8 || !GRP1) ? 4 : 3;
+      constexpr int NL = CONV ? 2 : ((MT == 8 || !GRP1) ? 4 : 3);
       for (int kt = 2; kt <= nk - 5; ++kt) {
+#ifndef WFL_ABL_NOLDS          // diagnostic builds (tools/gemm_lab.py): no fragment reads / no operand DMA in the steady loop
         read_frags();
+#endif
+#ifndef WFL_ABL_NOSTAGE
         issue_stage();
+#else
+        ++issued; ++pkt; if (CONV) { if (++ptap == ntaps) { ptap = 0; ++pcc; ++pccg; } }
+#endif
         if (GRP1) wait_vm<2 * NL>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
@@ -414,22 +467,22 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #undef SSB
 }
 
-template <int ACT, int MT, bool RES, int LNF, bool STATS>
+template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV = false>
 static int launch_stream(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
 #ifdef WFL_LAB_STB32
   constexpr int lds = SNST * 512 * SBK * 2 + 8 * (MT * 16) * 2 * 4 + 64;
 #else
-  constexpr int lds = SNST * (BMV + 256) * SBK * 2 + 8 * (MT * 16) * 2 * 4 + 64;
+  constexpr int lds = (CONV ? SNST * 256 * SBK * 2 + 2 * 224 * SBK * 2 : SNST * (BMV + 256) * SBK * 2) + 8 * (MT * 16) * 2 * 4 + 64;
 #endif
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
-  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS>;
+  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
     attr_set = true;
   }
-  g_wfl_gemm_kernel_id = MT == 6 ? 1 : 5;
+  g_wfl_gemm_kernel_id = CONV ? 6 : (MT == 6 ? 1 : 5);
   hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -446,6 +499,17 @@ static int launch_stream_mt(const GemmArgs& a, hipStream_t s) {
   if (forced == 256) return launch_stream<ACT, 8, RES, LNF, STATS>(a, s);
 #endif
   return launch_stream<ACT, 6, RES, LNF, STATS>(a, s);
+}
+
+// Dense multi-tap convolutions take the tap-stationary mode (template CONV): taps exactly one input row apart, at most 32
+// of them, whole 32-channel chunks, plain epilogue.  (Chosen by shape only -- never by batch size -- because its K order, and so
+// its rounding, differs from the other kernels'.)
+static bool wfl_gemm_stream_conv(const GemmArgs& a) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("WFL_GEMM_NO_CONV"); off = e && atoi(e) ? 1 : 0; }
+  if (off) return false;
+  return a.cin < a.K && a.K % a.cin == 0 && a.K / a.cin <= 32 && a.tap_stride == a.lda && a.cin % SBK == 0 && !a.res && !a.ln_s &&
+         !a.stats_out;
 }
 
 // The launches this kernel takes (everything else stays with gemm256 / gemm).
@@ -488,6 +552,14 @@ int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {
     switch (g.act) {
       case WFL_ACT_NONE: return launch_stream_mt<WFL_ACT_NONE, false, 1>(g, s);
       case WFL_ACT_GELU: return launch_stream_mt<WFL_ACT_GELU, false, 1>(g, s);
+    }
+    return 1;
+  }
+  if (wfl_gemm_stream_conv(g)) {
+    switch (g.act) {
+      case WFL_ACT_NONE: return launch_stream<WFL_ACT_NONE, 6, false, 0, false, true>(g, s);
+      case WFL_ACT_GELU: return launch_stream<WFL_ACT_GELU, 6, false, 0, false, true>(g, s);
+      case WFL_ACT_RELU: return launch_stream<WFL_ACT_RELU, 6, false, 0, false, true>(g, s);
     }
     return 1;
   }

@@ -1179,7 +1179,9 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
       // x = x + pw2(GELU(BN(conv_k(GLU(pw1(LN2(x)))))))
       R.ln(H, S, C.ln2);
       R.gemm(S + (long)p.lead * d, d, C.pw1, (int)Mrows, p.P, p.T, ATT, d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0, true);
-      R.gemm(ATT + (long)(p.lead - a.conformer_kernel / 2) * d, d, C.conv, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU);
+      // dense k-tap conv: taps are adjacent rows (cin = d, tap stride = one row) -> the streaming GEMM's tap-stationary mode
+      R.gemm(ATT + (long)(p.lead - a.conformer_kernel / 2) * d, d, C.conv, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU,
+             nullptr, 0, 1.f, d, d);
       R.gemm(S + (long)p.lead * d, d, C.pw2, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
       // x = x + 0.5 * FF2(x)
       R.ln_gemm(H, S, C.ff2_ln, C.ff2_a, C.ff2_a_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
@@ -1196,7 +1198,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     float* lg_pass = (n_pass > 1 && pass > 0) ? (float*)(R.ws + p.logits2) : lg;
     R.gemm(H + (long)p.lead * d, d, m->cls, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f, 0,
            0, false, true);
-    R.gemm(H + (long)(p.lead - 1) * d, d, m->off1, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU);
+    R.gemm(H + (long)(p.lead - 1) * d, d, m->off1, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0, 1.f, d, d);
     if (R.rc) return R.rc;
     TagArgs t{};
     t.rows = B * p.T; t.C = a.num_classes; t.threshold = threshold; t.o_id = a.o_id;
