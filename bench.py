@@ -168,16 +168,24 @@ def main():
         host_tags = host_bufs[slot]
         with torch.cuda.stream(streams[slot]):
             out = model.label(wav, lang, threshold=0.5, graph=graph, slot=slot)
-            if world > 1:
-                ids, maxp, offs = gather_tags(out.ids, out.maxprob, out.offsets, dst=0)
-                if rank != 0:
-                    return
-                n = ids.numel()
-                host_tags[0:n].copy_(ids.reshape(-1), non_blocking=True)
-                host_tags[n:2 * n].copy_(maxp.reshape(-1).view(torch.int32), non_blocking=True)
-                host_tags[2 * n:4 * n].copy_(offs.reshape(-1).view(torch.int32), non_blocking=True)
-            else:
+            if world == 1:
                 host_tags.copy_(out.packed, non_blocking=True)
+                return
+        # N > 1: the forward ran on stream `slot`; the collective and the host copy are issued from the main stream (every
+        # RCCL call of this process comes from one stream, in program order), which waits for that forward only
+        main = streams[0]
+        if slot:
+            main.wait_stream(streams[slot])
+            for t in (out.ids, out.maxprob, out.offsets):
+                t.record_stream(main)
+        with torch.cuda.stream(main):
+            ids, maxp, offs = gather_tags(out.ids, out.maxprob, out.offsets, dst=0)
+            if rank != 0:
+                return
+            n = ids.numel()
+            host_tags[0:n].copy_(ids.reshape(-1), non_blocking=True)
+            host_tags[n:2 * n].copy_(maxp.reshape(-1).view(torch.int32), non_blocking=True)
+            host_tags[2 * n:4 * n].copy_(offs.reshape(-1).view(torch.int32), non_blocking=True)
 
     def fence():
         if world > 1:
