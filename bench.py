@@ -159,6 +159,7 @@ def main():
     host_bufs = [torch.empty(n_host * T * 4, dtype=torch.int32).pin_memory() for _ in range(nfl)]   # ids | max-prob | offsets
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
     step_no = [0]
+    comm_stream = [torch.cuda.Stream(dev)] if world > 1 else [None]
 
     use_graph = args.graph
 
@@ -171,14 +172,14 @@ def main():
             if world == 1:
                 host_tags.copy_(out.packed, non_blocking=True)
                 return
-        # N > 1: the forward ran on stream `slot`; the collective and the host copy are issued from the main stream (every
-        # RCCL call of this process comes from one stream, in program order), which waits for that forward only
-        main = streams[0]
-        if slot:
-            main.wait_stream(streams[slot])
-            for t in (out.ids, out.maxprob, out.offsets):
-                t.record_stream(main)
-        with torch.cuda.stream(main):
+        # N > 1: the forward ran on stream `slot`; the collective and the host copy are issued from ONE separate stream (every
+        # RCCL call of this process comes from that stream, in program order), which waits for that forward only, so the next
+        # step's forward (other stream) still overlaps
+        comm = comm_stream[0]
+        comm.wait_stream(streams[slot])
+        for t in (out.ids, out.maxprob, out.offsets):
+            t.record_stream(comm)
+        with torch.cuda.stream(comm):
             ids, maxp, offs = gather_tags(out.ids, out.maxprob, out.offsets, dst=0)
             if rank != 0:
                 return
