@@ -23,6 +23,11 @@
 #define SEG ((FT - 1) * HOP + NFFT)        // 5360 samples
 #define SEG_LDS (SEG + SEG / HOP + 2)      // skewed
 #define PPITCH 225
+#ifdef WFL_LOGMEL_STAMPS
+#define LSTAMP(k) do { if (threadIdx.x == 0 && p.stamps) p.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LSTAMP(k) do { } while (0)
+#endif
 
 struct LogmelArgs {
   const float* wav; long ldw;       // [B][ldw]
@@ -33,6 +38,9 @@ struct LogmelArgs {
   const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
   float* raw;                       // [B][n_frames][n_mels] log10 mel
   unsigned* clipmax;                // [B] ordered-uint max of raw (zeroed by the caller)
+#ifdef WFL_LOGMEL_STAMPS
+  unsigned long long* stamps;       // diagnostic build (tools/micro/logmel_bench.hip): [blocks][8] 100 MHz phase stamps
+#endif
 };
 
 static __device__ __forceinline__ unsigned f2ord(float f) {
@@ -51,6 +59,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   const int b = blockIdx.y, f0 = blockIdx.x * FT;
   const int len = p.lens ? min(p.lens[b], min(p.L, p.n_samples)) : min(p.L, p.n_samples);
   const float* w = p.wav + (long)b * p.ldw;
+  LSTAMP(0);
 
   // ---- stage the signal segment: sample index i = 160*f0 - 200 + j, reflect about 0 and n_samples-1
   // All 41 loads of a thread are issued before the first LDS write (unconditional, index clamped, value selected afterwards):
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
     if (j < SEG) seg[j + j / HOP] = sv[it];
   }
   __syncthreads();
+  LSTAMP(1);
 
   // ---- DFT on the fp32 MFMA.  Lane l: A[row = l&31][k = l>>5], B[k = l>>5][col = l&31].
   // The periodic Hann window and the twiddles are symmetric about n = 200 (w[400-n] = w[n], cos(2 pi (400-n) k/400) =
@@ -138,7 +148,9 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
         pw[fr * PPITCH + ct * 32 + r] = re[rt][e] * re[rt][e] + im[rt][e] * im[rt][e];
       }
   }
+  LSTAMP(2);
   __syncthreads();
+  LSTAMP(3);
 
   // ---- sparse mel projection + log10; thread -> frame (tid % FT), mel bands (tid / FT) + (256 / FT) * i.
   // The filter table (weights, first bin, width per band: ~10 KB) moves into the now idle signal segment first: read from
@@ -170,6 +182,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
   if (lane == 0 && mx > -INFINITY) atomicMax(p.clipmax + b, f2ord(mx));
+  LSTAMP(4);
 }
 
 __global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restrict__ raw, const unsigned* __restrict__ clipmax,
