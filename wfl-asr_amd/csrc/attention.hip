@@ -33,9 +33,12 @@ static __device__ __forceinline__ int k_swz(int row) {
 template <int HD, int QT, bool PREFETCH, bool BIAS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                       // [KT][HD] bf16, 16-byte chunks XOR-swizzled
-  char* Vs = smem + KT * HD * 2;         // [KT][VPITCH]
   constexpr int VPITCH = HD * 2 + 32;
+  constexpr int TILE_BYTES = KT * HD * 2 + KT * VPITCH;   // K tile [KT][HD] (16-byte chunks XOR-swizzled) + V tile [KT][VPITCH]
+  // PREFETCH variants keep TWO tiles in LDS: tile kt+1 is written (from the registers its global loads landed in) right
+  // after tile kt's MFMAs, so a key tile costs one workgroup barrier instead of two
+  char* Ks = smem;
+  char* Vs = smem + KT * HD * 2;
   constexpr int CPR = HD / 8;
   constexpr int KCH = KT * CPR / 256;    // K (and V) chunks per thread per tile
   constexpr int KS = HD / 32;            // k-steps over head_dim
@@ -123,13 +126,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
   };
 
-  if (PREFETCH) load_tile(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();                     // every wave is done reading the previous tile
-    if (!PREFETCH) load_tile(kt);
-    store_tile();
+  if (PREFETCH) {
+    load_tile(0);
+    store_tile();                        // tile 0 -> buffer 0
+    if (ntiles > 1) load_tile(1);        // in flight under tile 0's MFMAs
     __syncthreads();
-    if (PREFETCH && kt + 1 < ntiles) load_tile(kt + 1);   // in flight under this tile's MFMAs
+  }
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (!PREFETCH) {
+      __syncthreads();                   // every wave is done reading the previous tile
+      load_tile(kt);
+      store_tile();
+      __syncthreads();
+    } else {
+      Ks = smem + (kt & 1) * TILE_BYTES;
+      Vs = Ks + KT * HD * 2;
+    }
 
     // ---- S^T = K . Q^T : st[qt][kk][e] = score(query q0+16qt+c, key 64kt + 16kk + 4g + e)
     f32x4 st[QT][4];
@@ -245,6 +257,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
       }
     }
+    if (PREFETCH && kt + 1 < ntiles) {
+      // tile kt+1 (in registers since the previous iteration) -> the other buffer, which every wave left before the last
+      // barrier; then start tile kt+2's loads
+      Ks = smem + ((kt + 1) & 1) * TILE_BYTES;
+      Vs = Ks + KT * HD * 2;
+      store_tile();
+      if (kt + 2 < ntiles) load_tile(kt + 2);
+      __syncthreads();
+    }
   }
 
   // ---- normalise and store: lane holds channels h*HD + 16dt + 4g + e of query frame q0 + 16qt + c
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
 template <int HD, int QT, bool PREFETCH, bool BIAS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
-  constexpr int lds = KT * HD * 2 + KT * (HD * 2 + 32);
+  constexpr int lds = (PREFETCH ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32));
   auto k = attn_kernel<HD, QT, PREFETCH, BIAS>;
   static bool attr_set = false;
   if (!attr_set) {
