@@ -240,8 +240,8 @@ def main():
                     return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
                                                                            tf(kid == 6))
                 if kid in (2, 3):
-                    return "gemm256_kernel<%d, %s, %s, %d, false>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
-                return "gemm_bf16_kernel<%d, %s, %s, false>" % (acts[act], tf(glu), tf(f32))
+                    return "gemm256_kernel<%d, %s, %s, %d>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
+                return "gemm_bf16_kernel<%d, %s, %s>" % (acts[act], tf(glu), tf(f32))
 
             tot_ms = sum(p["ms"] for p in prof)
             tot_fl = sum(p["flops"] for p in prof)

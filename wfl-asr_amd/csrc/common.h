@@ -51,8 +51,6 @@ struct GemmArgs {
   int act;
   int glu;                  // weights row-interleaved in groups of 16 (a | gate); N_out = N / 2
   int out_f32;
-  bf16_t* Vt;               // columns >= vt_n0 are written transposed: Vt[(b * (n_valid - vt_n0) + n - vt_n0) * P + t]
-  int vt_n0;                // (multiple of 128); frames t in [T, P) of Vt are written as zero
   const float* ln_s;        // LayerNorm folded in front of the GEMM (gemm_stream.hip): s[n] = sum_k W'[n][k], W' = gamma o W,
   float ln_eps;             //   bias = b + W beta;  out = rstd_m * (acc - mean_m * s[n]) + bias[n];  statistics over the K columns
   float* stats_out;         // residual launches (gemm_stream.hip): per output row, per 256-column tile, (sum, sum of squares) of

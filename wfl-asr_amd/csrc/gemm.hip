@@ -10,8 +10,7 @@
 // the read (chunk' = chunk ^ ((row >> 1) & 7) on 128-byte rows).
 //
 // MFMA roles are transposed (A operand = weight rows, B operand = frame rows), so each lane ends up with 4
-// consecutive output channels of one frame and stores 8 bytes; blocks in the V range of a packed q|k|v
-// projection swap the roles back and write V transposed ([channel][frame]) for the attention kernel's P.V.
+// consecutive output channels of one frame and stores 8 bytes.
 #include "common.h"
 #include <cstdlib>
 
@@ -40,7 +39,7 @@ static __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-template <int ACT, bool GLU, bool OUTF32, bool VT>
+template <int ACT, bool GLU, bool OUTF32>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -100,8 +99,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bool swap_roles = VT && p.Vt != nullptr && n0 >= p.vt_n0;   // block-uniform
-
   // bias for this lane's 4x4 channels (normal roles), fetched before the K loop so its latency is off the epilogue
   f32x4 bj[4];
 #pragma unroll
@@ -118,10 +115,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   //     wave finished kt-1)
   //     read F0 = (kt+1, k 0..31) | 16 MFMA on F1
   //
-  // acc[u][v] = mfma(FA[v], FB[u]); FA rows come from the weight tile and FB rows from the frame tile (D[n][m]),
-  // or the other way round (D[m][n]) for blocks that write V transposed: the roles are just LDS offsets.
-  const int fa_off = (swap_roles ? 0 : BM * BK * 2) + (swap_roles ? wm : wn) * 128;
-  const int fb_off = (swap_roles ? BM * BK * 2 : 0) + (swap_roles ? wn : wm) * 128;
+  // acc[u][v] = mfma(FA[v], FB[u]); FA rows come from the weight tile and FB rows from the frame tile (D[n][m])
+  const int fa_off = BM * BK * 2 + wn * 128;
+  const int fb_off = wm * 128;
   bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
 #define LOAD_FRAGS(FA, FB, slot, s)                                                              \
   do {                                                                                           \
@@ -200,43 +196,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     p.stamps[(long)blockIdx.x * 8 + 7] = hwid;
   }
 #endif
-  if (VT && swap_roles) {
-    // acc[i][j][e]: frame m = wm+16i+4g+e, channel n = wn+16j+c  ->  staged transposed [n][m]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nl = wn + j * 16 + (lane & 15);
-      const float bv = p.bias ? p.bias[n0 + nl] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v = acc[j][i];                  // swapped roles: acc[u][v] with u = channel tile, v = frame tile
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bv;
-        *(f32x4*)(stg + nl * EP + wm + i * 16 + (lane >> 4) * 4) = v;
-      }
-    }
-    __syncthreads();
-    const int nv = p.n_valid - p.vt_n0;       // channels in the transposed block (N is padded)
-    const int cidx = tid & 15;
-    const int m = m0 + cidx * 8;
-    const int b = m / p.P, t = m - b * p.P;   // 8 frames from a multiple of 8 never straddle clips (P % 8 == 0)
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int r = pass * 16 + (tid >> 4);
-      const int n = n0 + r;
-      if (n >= p.n_valid || m >= p.M) continue;
-      const f32x4 v0 = *(const f32x4*)(stg + r * EP + cidx * 8);
-      const f32x4 v1 = *(const f32x4*)(stg + r * EP + cidx * 8 + 4);
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = f2bf(t + e < p.T ? v0[e] : 0.f);
-        o[4 + e] = f2bf(t + 4 + e < p.T ? v1[e] : 0.f);
-      }
-      *(bf16x8*)(p.Vt + ((long)b * nv + (n - p.vt_n0)) * p.P + t) = o;
-    }
-    return;
-  }
-
   // stage 1: acc[i][j][e] is frame m = wm+16i+c, channel n = wn+16j+4g+e
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -351,10 +310,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   STAMP(4);
 }
 
-template <int ACT, bool GLU, bool OUTF32, bool VT>
+template <int ACT, bool GLU, bool OUTF32>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  auto k = gemm_bf16_kernel<ACT, GLU, OUTF32, VT>;
+  auto k = gemm_bf16_kernel<ACT, GLU, OUTF32>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -2;
@@ -381,7 +340,7 @@ static int tile_pref() {
 
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.N % BN || a.K <= 0 || a.K % BK || a.cin <= 0 || a.cin % BK || a.P <= 0 || a.P % 8 ||
-      (!a.out_f32 && a.ldc % 8) || (a.res && a.ldres % 8) || (a.pos && a.ldpos % 8) || (a.Vt && a.vt_n0 % BN))
+      (!a.out_f32 && a.ldc % 8) || (a.res && a.ldres % 8) || (a.pos && a.ldpos % 8))
     return -1;
   if (tile_pref() == 256) {
     int r = wfl_launch_gemm_stream(a, s);
@@ -392,23 +351,19 @@ int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
   }
   if (a.ln_s) return -1;
   if (a.glu) {
-    if (a.out_f32 || a.act != WFL_ACT_NONE || a.Vt) return -1;
-    return launch_t<WFL_ACT_NONE, true, false, false>(a, s);
-  }
-  if (a.Vt) {
     if (a.out_f32 || a.act != WFL_ACT_NONE) return -1;
-    return launch_t<WFL_ACT_NONE, false, false, true>(a, s);
+    return launch_t<WFL_ACT_NONE, true, false>(a, s);
   }
   if (a.out_f32) {
-    if (a.act == WFL_ACT_NONE) return launch_t<WFL_ACT_NONE, false, true, false>(a, s);
-    if (a.act == WFL_ACT_SIGMOID) return launch_t<WFL_ACT_SIGMOID, false, true, false>(a, s);
+    if (a.act == WFL_ACT_NONE) return launch_t<WFL_ACT_NONE, false, true>(a, s);
+    if (a.act == WFL_ACT_SIGMOID) return launch_t<WFL_ACT_SIGMOID, false, true>(a, s);
     return -1;
   }
   switch (a.act) {
-    case WFL_ACT_NONE: return launch_t<WFL_ACT_NONE, false, false, false>(a, s);
-    case WFL_ACT_GELU: return launch_t<WFL_ACT_GELU, false, false, false>(a, s);
-    case WFL_ACT_RELU: return launch_t<WFL_ACT_RELU, false, false, false>(a, s);
-    case WFL_ACT_SIGMOID: return launch_t<WFL_ACT_SIGMOID, false, false, false>(a, s);
+    case WFL_ACT_NONE: return launch_t<WFL_ACT_NONE, false, false>(a, s);
+    case WFL_ACT_GELU: return launch_t<WFL_ACT_GELU, false, false>(a, s);
+    case WFL_ACT_RELU: return launch_t<WFL_ACT_RELU, false, false>(a, s);
+    case WFL_ACT_SIGMOID: return launch_t<WFL_ACT_SIGMOID, false, false>(a, s);
   }
   return -1;
 }

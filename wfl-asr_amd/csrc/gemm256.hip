@@ -1,5 +1,4 @@
-// 256 x 256 x 32 variant of the bf16 MFMA GEMM (same contract and epilogues as gemm.hip; the V^T columns of a packed
-// q|k|v projection are transposed through LDS instead of by swapping MFMA operand roles).
+// 256 x 256 x 32 variant of the bf16 MFMA GEMM (same contract and epilogues as gemm.hip).
 //
 // Why: tools/gemm_diag.py shows the 128x128 tile is bound by L2 -> LDS bandwidth per CU (~50-70 GB/s): each K step
 // moves 32 KiB for 2.1 MFLOP.  A 256x256 block tile moves the same 32 KiB per 32-deep K step for 4.2 MFLOP, i.e. twice
@@ -23,7 +22,7 @@
 #define ST2 (2 * 256 * BK2 * 2)          // one stage: frame tile + weight tile = 32 KiB
 #define NST2 4
 #define EP2 260                           // epilogue pitch (floats)
-#define LDS2 (256 * 132 * 4)              // 135,168 B: the transposed V^T staging tile (>= 128 * EP2 * 4 >= NST2 * ST2)
+#define LDS2 (256 * 132 * 4)              // 135,168 B (>= 128 * EP2 * 4 epilogue staging >= NST2 * ST2 operand ring)
 
 typedef __attribute__((address_space(1))) const void* gptr2_t;
 typedef __attribute__((address_space(3))) void* lptr2_t;
@@ -39,7 +38,7 @@ static __device__ __forceinline__ int swz2(int row) { return (-(row >> 2)) & 3; 
 #define STAMP2(k) do { } while (0)
 #endif
 
-template <int ACT, bool GLU, bool OUTF32, int MT, bool VT>   // MT = 16-frame MFMA tiles per wave: 8 -> 256-row block, 6 -> 192
+template <int ACT, bool GLU, bool OUTF32, int MT>   // MT = 16-frame MFMA tiles per wave: 8 -> 256-row block, 6 -> 192
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   constexpr int BMV = MT * 32;              // rows of the block tile that are computed (the staged tile is always 256 rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,48 +217,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
   }
 
-  const bool vtblk = VT && p.Vt != nullptr && n0 >= p.vt_n0;   // block-uniform: this block's columns are V
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     __syncthreads();                          // operand ring / previous half fully consumed
-    if (VT && vtblk) {
-      // V columns of a packed q|k|v projection leave TRANSPOSED ([channel][frame], the layout attention's P.V wants):
-      // the half tile is staged as [256 channels][HR frames] (scalar LDS writes, lanes along frames), then every
-      // thread moves 8 consecutive frames of one channel = 16 contiguous bytes of Vt.
-      constexpr int EPT = HR + 4;
-      if ((wid >> 2) == half) {
-#pragma unroll
-        for (int u = 0; u < MT; ++u)
-#pragma unroll
-          for (int v4 = 0; v4 < 4; ++v4)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              stg[(wn + v4 * 16 + (lane >> 4) * 4 + e) * EPT + u * 16 + (lane & 15)] = acc[u][v4][e];
-      }
-      __syncthreads();
-      const int mc = tid & 15;
-      const int m = m0 + half * HR + mc * 8;
-      if (mc * 8 < HR && m < p.M) {
-        const int b = m / p.P, t = m - b * p.P;
-        const int nv = p.n_valid - p.vt_n0;
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-          const int nl = pass * 32 + (tid >> 4);
-          const int n = n0 + nl;
-          if (n >= p.n_valid) continue;
-          const f32x4 v0 = *(const f32x4*)(stg + nl * EPT + mc * 8);
-          const f32x4 v1 = *(const f32x4*)(stg + nl * EPT + mc * 8 + 4);
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = f2bf(t + e < p.T ? v0[e] : 0.f);
-            o[4 + e] = f2bf(t + 4 + e < p.T ? v1[e] : 0.f);
-          }
-          *(bf16x8*)(p.Vt + ((long)b * nv + (n - p.vt_n0)) * p.P + t) = o;
-        }
-      }
-      continue;
-    }
     if ((wid >> 2) == half) {
       // acc[u][v][e]: frame ml = 16u + c, channel nl = wn + 16v + 4g + e
 #pragma unroll
@@ -359,11 +319,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   STAMP2(4);
 }
 
-template <int ACT, bool GLU, bool OUTF32, int MT, bool VT>
+template <int ACT, bool GLU, bool OUTF32, int MT>
 static int launch256_mt(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / BN2);
-  auto k = gemm256_kernel<ACT, GLU, OUTF32, MT, VT>;
+  auto k = gemm256_kernel<ACT, GLU, OUTF32, MT>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return -2;
@@ -376,7 +336,7 @@ static int launch256_mt(const GemmArgs& a, hipStream_t s) {
 
 // Block height: 256 or 192 rows, whichever fills the 256 CUs in fewer / fuller rounds (one block per CU).  Cost model:
 // rounds * (rows + fixed per-block overhead worth ~96 rows).
-template <int ACT, bool GLU, bool OUTF32, bool VT = false>
+template <int ACT, bool GLU, bool OUTF32>
 static int launch256_t(const GemmArgs& a, hipStream_t s) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0; }
@@ -385,16 +345,12 @@ static int launch256_t(const GemmArgs& a, hipStream_t s) {
     return ((tiles + 255) / 256) * (long)(bm + 96);
   };
   const bool use192 = forced == 192 || (forced != 256 && cost(192) < cost(256));
-  return use192 ? launch256_mt<ACT, GLU, OUTF32, 6, VT>(a, s) : launch256_mt<ACT, GLU, OUTF32, 8, VT>(a, s);
+  return use192 ? launch256_mt<ACT, GLU, OUTF32, 6>(a, s) : launch256_mt<ACT, GLU, OUTF32, 8>(a, s);
 }
 
 // Returns 1 when this kernel does not take the shape (caller falls back to the 128x128 kernel).
 int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s) {
   if (a.N % BN2 || a.K % BK2 || a.cin % BK2 || a.M < 2048) return 1;
-  if (a.Vt) {
-    if (a.vt_n0 % BN2 || a.P % 8 || a.glu || a.out_f32 || a.act != WFL_ACT_NONE || a.res || a.pos || a.clip_bias) return 1;
-    return launch256_t<WFL_ACT_NONE, false, false, true>(a, s);
-  }
   if (a.glu) return launch256_t<WFL_ACT_NONE, true, false>(a, s);
   if (a.out_f32) {
     if (a.act == WFL_ACT_NONE) return launch256_t<WFL_ACT_NONE, false, true>(a, s);
