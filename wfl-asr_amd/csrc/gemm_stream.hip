@@ -1,4 +1,4 @@
-// Persistent ("streaming") 256 x 256 x 32 bf16 MFMA GEMM for gfx950 -- the main kernel behind the Linear / Conv1d layers of
+// Persistent ("streaming") 192 x 256 x 32 bf16 MFMA GEMM for gfx950 -- the main kernel behind the Linear / Conv1d layers of
 // the WFL-ASR forward whose output is bf16 with a plain epilogue (bias, GELU/ReLU, residual, optionally a LayerNorm
 // folded in front).  Same GemmArgs contract as gemm.hip / gemm256.hip, which keep the GLU, fp32-output, positional-table
 // and per-clip-bias launches.  Replaces /root/reference/model.py:18-19, 26, 31-37, 131, 140 and HF
@@ -18,10 +18,15 @@
 //   * each wave group runs the previous tile's epilogue at the start of its first L slot of the next tile, i.e. while the
 //     other group owns the matrix pipe;
 //   * LayerNorm folding (GemmArgs::ln_s != null):  LN(x) W^T + b = rstd * (x W'^T - mean * s) + b'  with W' = gamma o W,
-//     s_n = sum_k W'_nk, b' = b + W beta (packed at load time).  The row statistics come from the very fragments the
-//     MFMAs consume: in every C slot each wave adds up its share of the frame fragments with v_dot2c_f32_bf16 (sum and
-//     sum of squares, fp32), the four waves of a group exchange the 16-frame partials through 1 KiB of LDS at the end
-//     of the tile, and the epilogue applies the affine correction -- the LayerNorm costs no launch and no HBM pass.
+//     s_n = sum_k W'_nk, b' = b + W beta (packed at load time).  The row statistics either come from the GEMM that produced
+//     x (template STATS on its residual epilogue: per row and 256-column tile, sum and sum of squares of the bf16 values it
+//     stores; the four waves' partials meet in LDS and the last arriver -- an LDS ticket, no barrier -- adds them in a fixed
+//     order and writes them; the consumer, LNF = 2, reads them in its epilogue), or are summed inside the consumer from the
+//     fragments its MFMAs consume (LNF = 1, v_dot2c_f32_bf16 in the C slots; measured slower, kept for experiments);
+//   * a tap-stationary mode for dense multi-tap convolutions (template CONV, see the kernel).
+// The K loop itself is bound by the L2 -> LDS operand DMA (28 KiB per 32-deep step of a 192 x 256 tile; ~65 GB/s per CU) next
+// to 24 MFMAs per wave: tools/gemm_lab.py's ablations give 0.40 us per step for the MFMAs alone, 0.45-0.50 us for the DMA
+// alone and 0.59-0.64 us for the real loop.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
