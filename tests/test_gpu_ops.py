@@ -377,3 +377,21 @@ def test_gemm_stream_dense_conv_tap_stationary(C, k, N, act):
     ref = [ref, F.gelu(ref), F.relu(ref)][act]
     _close(out.get(), ref, what="tap-stationary conv")
     assert out.halo_is_zero()
+
+
+@pytest.mark.parametrize("B,T,C,k,N", [(16, 1500, 128, 3, 2048), (32, 1500, 64, 31, 512)])
+def test_gemm_stream_dense_conv_several_tiles_per_workgroup(B, T, C, k, N):
+    """the tap-stationary mode with more tiles than CUs: the channel-chunk buffers, tap counters and the operand stream carry
+    over from one tile to the next inside a persistent workgroup (a batch of 32 clips puts the k = 31 Conformer conv here)."""
+    x0 = _rand(B, T, C, seed=91)
+    a = G.Rows(B, T, C, halo=32, lead=32).set(x0)
+    w, bias = _rand(N, C, k, scale=(k * C) ** -0.5, seed=92), _rand(N, scale=0.1, seed=93)
+    wp, bp = G.pad_weight(w.permute(0, 2, 1).reshape(N, k * C), bias)
+    out = G.Rows(B, T, N, halo=32, lead=32)
+    assert ((B * a.P + 191) // 192) * (N // 256) > 256
+    left = (k - 1) // 2
+    G.gemm(a.buf, (a.lead - left) * C, C, wp, B * a.P, N, a.P, T, out.buf, N, out.lead, out.P, bias=bp, act=1, cin=C, tap_stride=C)
+    torch.cuda.synchronize()
+    ref = F.gelu(F.conv1d(F.pad(_bf(x0).transpose(1, 2), (left, k - 1 - left)), _bf(w), bias)).transpose(1, 2)
+    _close(out.get(), ref, what="tap-stationary conv, several tiles per workgroup")
+    assert out.halo_is_zero()
