@@ -141,7 +141,7 @@ def main():
 
     from wfl_asr_amd import synth
     from wfl_asr_amd.tagger import BIOPhonemeTagger
-    from wfl_asr_amd.dist import gather_tags
+    from wfl_asr_amd.dist import gather_packed
 
     cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(args.config_index)
     labels = synth.make_labels(70)
@@ -154,13 +154,14 @@ def main():
     wav = torch.from_numpy(synth.make_batch(10000 + rank * B, B, L, seed=1)).to(dev)     # resident in HBM
     lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
     T = model.num_frames(L)
-    n_host = B * (world if rank == 0 else 1)
+    words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
     nfl = max(1, args.inflight)
-    host_bufs = [torch.empty(n_host * T * 4, dtype=torch.int32).pin_memory() for _ in range(nfl)]   # ids | max-prob | offsets
+    host_bufs = [torch.empty((world if rank == 0 else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
     step_no = [0]
     multi = world > 1 or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))     # (the env var walks the N > 1 code path on one rank)
     comm_stream = [torch.cuda.Stream(dev)] if multi else [None]
+    gather_bufs = [torch.empty(world, words, dtype=torch.int32, device=dev) for _ in range(nfl)] if (multi and rank == 0) else None
 
     use_graph = args.graph
 
@@ -171,23 +172,18 @@ def main():
         with torch.cuda.stream(streams[slot]):
             out = model.label(wav, lang, threshold=0.5, graph=graph, slot=slot)
             if not multi:
-                host_tags.copy_(out.packed, non_blocking=True)
+                host_tags[0].copy_(out.packed, non_blocking=True)
                 return
         # N > 1: the forward ran on stream `slot`; the collective and the host copy are issued from ONE separate stream (every
         # RCCL call of this process comes from that stream, in program order), which waits for that forward only, so the next
         # step's forward (other stream) still overlaps
         comm = comm_stream[0]
         comm.wait_stream(streams[slot])
-        for t in (out.ids, out.maxprob, out.offsets):
-            t.record_stream(comm)
+        out.packed.record_stream(comm)
         with torch.cuda.stream(comm):
-            ids, maxp, offs = gather_tags(out.ids, out.maxprob, out.offsets, dst=0)
-            if rank != 0:
-                return
-            n = ids.numel()
-            host_tags[0:n].copy_(ids.reshape(-1), non_blocking=True)
-            host_tags[n:2 * n].copy_(maxp.reshape(-1).view(torch.int32), non_blocking=True)
-            host_tags[2 * n:4 * n].copy_(offs.reshape(-1).view(torch.int32), non_blocking=True)
+            rows = gather_packed(out.packed, dst=0, out=gather_bufs[slot] if rank == 0 else None)   # ONE collective, no re-packing
+            if rank == 0:
+                host_tags.copy_(rows, non_blocking=True)
 
     def fence():
         if world > 1:

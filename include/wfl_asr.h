@@ -9,7 +9,9 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
  *     enqueued on it and nothing here synchronises the device;
  *   - return value 0 = ok, negative = error (wfl_last_error() gives the text); no exceptions cross the ABI;
- *   - one model handle per process per GPU; a handle is not re-entrant.
+ *   - one model handle per process per GPU; a handle is not re-entrant.  A model lives on the HIP device that was current
+ *     when wfl_finalize ran (wfl_device()); every later call must be made with that device current and with buffers and
+ *     stream of that device (checked: a mismatch is an error, not a cross-device access).
  */
 #ifndef WFL_ASR_H
 #define WFL_ASR_H
@@ -25,7 +27,7 @@ typedef struct wfl_model wfl_model;
 #define WFL_ENC_WHISPER 0
 #define WFL_ENC_WAVLM 1
 
-#define WFL_ABI_VERSION 1
+#define WFL_ABI_VERSION 2
 
 /* Architecture = what /root/reference/model.py:54-146 reads from config.yaml plus the HF encoder config it
  * fetches by name (model.py:69-70, 74-80).  All int32, 64 slots, zero-initialise then fill. */
@@ -84,6 +86,14 @@ int32_t wfl_load_tensor(wfl_model* m, const char* name, const float* data_host, 
  * is immutable.  Missing or unexpected keys are an error, as with strict loading. */
 int32_t wfl_finalize(wfl_model* m);
 
+/* HIP device ordinal the weights were uploaded to by wfl_finalize (-1 before). */
+int32_t wfl_device(const wfl_model* m);
+
+/* The language ids WFL_LANG_AVERAGE averages over: the reference loops over the ids listed in langs.txt
+ * (/root/reference/infer.py:147-156, 266-276), which may be a subset of the embedding rows.  Default: every id
+ * 0 .. num_languages-1.  ids_host: n host int32, each in [0, num_languages). */
+int32_t wfl_set_average_languages(wfl_model* m, const int32_t* ids_host, int32_t n);
+
 /* Output frames for L input samples per clip (Whisper: always max_positions; WavLM: conv arithmetic). */
 int32_t wfl_num_frames(const wfl_model* m, int32_t L);
 int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
@@ -103,14 +113,29 @@ int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
  *   offsets    [B][T][2] fp32 sigmoid sub-frame offsets
  *   logits     [B][T][C] fp32                                (optional)
  *   hidden     [B][T][d] fp32 encoder output                 (optional, parity tests)
+ *   status     [1] int32 (device, optional): 0, or a bit mask of device-side errors of THIS forward (bit 0: an
+ *              inter-workgroup wait of the BiLSTM recurrence timed out -- the tags are invalid).  Written by the last kernel
+ *              of the forward, so it can ride in the same D2H copy as the tags.
  */
 int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,
                     const int32_t* lang_id, int32_t lang_mode, float threshold, void* workspace,
                     int64_t workspace_bytes, int32_t* ids, int32_t* argmax, float* maxprob, float* offsets,
-                    float* logits, float* hidden, void* stream);
+                    float* logits, float* hidden, int32_t* status, void* stream);
 
-/* Synchronise `stream` and report deferred device-side errors of the last wfl_forward on this workspace (today: a
- * timed-out inter-workgroup wait of the persistent BiLSTM kernel).  Optional; 0 = ok. */
+/* The two halves of wfl_forward, for callers that work on the encoder output in between -- the reference's training-time
+ * validation forward pads / truncates hidden_states to max_label_len frames before the head (model.py:166-174).
+ *   wfl_encode: model.py:149-161 (feature extractor + encoder) -> hidden [B][T][d] fp32, T = wfl_num_frames(L).
+ *   wfl_head:   model.py:176-194 + the tag decision on hidden [B][T][d] fp32 with ANY T >= 1 (outputs as wfl_forward);
+ *               workspace size from wfl_head_workspace_bytes(B, T). */
+int32_t wfl_encode(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L, void* workspace,
+                   int64_t workspace_bytes, float* hidden, void* stream);
+int64_t wfl_head_workspace_bytes(const wfl_model* m, int32_t B, int32_t T);
+int32_t wfl_head(wfl_model* m, const float* hidden, int32_t B, int32_t T, const int32_t* lang_id, int32_t lang_mode,
+                 float threshold, void* workspace, int64_t workspace_bytes, int32_t* ids, int32_t* argmax, float* maxprob,
+                 float* offsets, float* logits, int32_t* status, void* stream);
+
+/* Synchronise `stream` and report the device-side error word of the last forward run on this workspace (same bits as
+ * `status`: every kernel of a forward ORs into one word that the forward clears when it starts).  Optional; 0 = ok. */
 int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_t B, int32_t L, void* stream);
 
 /* ---- single stages, exported for unit parity tests and profiling ---- */

@@ -77,3 +77,62 @@ def test_gather_tags_world2_gloo(counts):
         exp_mp.append(torch.rand(counts[r], T, generator=g))
         exp_off.append(torch.rand(counts[r], T, 2, generator=g))
     assert torch.equal(a, torch.cat(exp_ids)) and torch.equal(b, torch.cat(exp_mp)) and torch.equal(c, torch.cat(exp_off))
+
+
+def _worker_packed(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, T = 3, 29
+        g = torch.Generator().manual_seed(500 + rank)
+        blob = torch.randint(-2 ** 31, 2 ** 31 - 1, (4 * n * T + 1,), generator=g, dtype=torch.int64).to(torch.int32)
+        out = wd.gather_packed(blob, dst=0)
+        if rank == 0:
+            q.put(out)
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_packed_world2_gloo_is_one_bit_exact_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n, T = 3, 29
+    assert out.shape == (2, 4 * n * T + 1)
+    for r in range(2):
+        g = torch.Generator().manual_seed(500 + r)
+        blob = torch.randint(-2 ** 31, 2 ** 31 - 1, (4 * n * T + 1,), generator=g, dtype=torch.int64).to(torch.int32)
+        assert torch.equal(out[r], blob)
+        ids, mp_, off, st = wd.split_packed(out[r], n, T)
+        assert ids.shape == (n, T) and mp_.shape == (n, T) and off.shape == (n, T, 2) and st.numel() == 1
+        assert torch.equal(ids.reshape(-1), blob[:n * T]) and int(st) == int(blob[-1])
+        assert torch.equal(off.reshape(-1).view(torch.int32), blob[2 * n * T:4 * n * T])
+
+
+def test_gather_packed_single_rank_is_a_view():
+    blob = torch.arange(4 * 2 * 5 + 1, dtype=torch.int32)
+    out = wd.gather_packed(blob)
+    assert out.shape == (1, blob.numel()) and out.data_ptr() == blob.data_ptr()
+
+
+def test_pick_device_follows_local_rank(monkeypatch):
+    """infer_folder under torchrun: a bare "cuda" must resolve to cuda:LOCAL_RANK, not to device 0 on every rank."""
+    from wfl_asr_amd import infer
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert infer.pick_device("cuda") == torch.device("cuda", 3)
+    assert infer.pick_device("cuda:1") == torch.device("cuda", 1)      # an explicit index wins
+    with pytest.raises(RuntimeError):
+        infer.pick_device("cpu")

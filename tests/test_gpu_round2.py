@@ -1,0 +1,178 @@
+"""-m gpu: round-2 additions to the boundary -- graph replay per workspace slot on concurrent streams, the forward's status
+word, the wfl_encode / wfl_head split with the reference's `max_label_len` pad / truncate (model.py:166-174), the language
+list `lang_id=None` averages over (infer.py:147-156), and the pipelined product loop with several batches in flight."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import wfl_oracle as O
+from wfl_asr_amd import audio as A
+from wfl_asr_amd import infer as I
+from wfl_asr_amd import synth
+from wfl_asr_amd.archs import resolve_encoder_arch
+from wfl_asr_amd.tagger import BIOPhonemeTagger
+from cases import tiny_whisper_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cfg, n_phonemes, seed):
+    labels = synth.make_labels(n_phonemes)
+    sd_np = synth.make_state_dict(cfg, len(labels), seed=seed)
+    m = BIOPhonemeTagger(cfg, labels)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.to("cuda").eval()
+    return m, labels, sd_np
+
+
+def test_graph_replay_two_slots_on_two_streams_cfg2_full_size():
+    """BASELINE config 2 at full size (16 x 30 s), two workspace slots, each with its own captured graph, replayed
+    CONCURRENTLY on two streams (what `bench.py --graph --inflight 2` does) and, on slot 0, a second signature (B = 8)
+    sharing the tagger: every replay equals the eager forward of the same batch bit for bit.  Round 1's divergence was
+    one graph (keyed without the slot) being replayed on both streams at once."""
+    cfg = synth.baseline_config(1)
+    m, labels, _ = _build(cfg, 70, seed=1)
+    B, L = 16, 480000
+    xs = [torch.from_numpy(synth.make_batch(3000 + 100 * i, B, L, seed=1)).cuda() for i in range(2)]
+    lang = (np.arange(B) % 2).astype(np.int64)
+    eager = [m.label(x, lang, threshold=0.5, want_logits=True) for x in xs]
+    eager8 = m.label(xs[1][:8], lang[:8], threshold=0.5, want_logits=True)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = [None, None]
+        for slot in (0, 1):
+            streams[slot].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[slot]):
+                # slot s labels batch (s + rep) % 2, so a graph sees both inputs over the repetitions
+                outs[slot] = m.label(xs[(slot + rep) % 2], lang, threshold=0.5, want_logits=True, graph=True, slot=slot)
+        torch.cuda.synchronize()
+        for slot in (0, 1):
+            e = eager[(slot + rep) % 2]
+            assert torch.equal(outs[slot].logits, e.logits), (rep, slot)
+            assert torch.equal(outs[slot].ids, e.ids) and torch.equal(outs[slot].offsets, e.offsets)
+            assert int(outs[slot].status.item()) == 0
+        g8 = m.label(xs[1][:8], lang[:8], threshold=0.5, want_logits=True, graph=True, slot=0)    # second signature, same slot
+        torch.cuda.synchronize()
+        assert torch.equal(g8.logits, eager8.logits) and torch.equal(g8.ids, eager8.ids)
+
+
+def test_status_word_rides_behind_the_tags():
+    cfg = tiny_whisper_config(enable_bilstm=True)
+    m, labels, _ = _build(cfg, 5, seed=61)
+    x = torch.from_numpy(synth.make_batch(800, 3, 32000, seed=61)).cuda()
+    out = m.label(x, [0, 1, 0], threshold=0.5)
+    n = out.ids.numel()
+    assert out.packed.numel() == 4 * n + 1 and out.status.data_ptr() == out.packed[4 * n:].data_ptr()
+    host = out.packed.cpu()
+    assert int(host[4 * n]) == 0
+    assert torch.equal(host[:n].view(3, -1), out.ids.cpu())
+    assert torch.equal(host[n:2 * n].view(torch.float32).view(3, -1), out.maxprob.cpu())
+    m.check(3, 32000)
+
+
+@pytest.mark.parametrize("enc", ["whisper", "wavlm"])
+def test_encode_head_split_and_max_label_len(enc):
+    """wfl_encode + wfl_head == wfl_forward bit for bit; forward(max_label_len) pads with zero frames / truncates the
+    encoder output before the head exactly as model.py:166-174 (checked against the oracle's head on the padded states)."""
+    if enc == "whisper":
+        cfg = tiny_whisper_config(enable_bilstm=True)
+        L = 32000
+    else:
+        from cases import tiny_wavlm_config
+        cfg = tiny_wavlm_config(True, enable_bilstm=False)
+        L = 16000
+    m, labels, sd_np = _build(cfg, 5, seed=62)
+    wav = synth.make_batch(810, 2, L, seed=62)
+    x = torch.from_numpy(wav).cuda()
+    lang = np.array([1, 0], np.int64)
+    whole = m.label(x, lang, threshold=0.4, want_logits=True, want_hidden=True)
+    hid = m.encode(x)
+    assert torch.equal(hid, whole.hidden)
+    part = m.head(hid, lang, threshold=0.4, want_logits=True)
+    assert torch.equal(part.logits, whole.logits) and torch.equal(part.ids, whole.ids) and torch.equal(part.offsets, whole.offsets)
+    assert int(part.status.item()) == 0
+    T = hid.size(1)
+    enc_name, arch = resolve_encoder_arch(cfg["model"])
+    sd = O.to_torch_state_dict(sd_np)
+    hc = synth.head_config(cfg["model"])
+    _, _, hid_ref = O.forward(torch.from_numpy(wav), torch.from_numpy(lang), sd, enc_name, arch, hc, return_hidden=True)
+    for mll in (T + 7, T - 9, T):
+        lg, of = m(x, torch.from_numpy(lang), max_label_len=mll)
+        assert tuple(lg.shape) == (2, mll, len(labels)) and tuple(of.shape) == (2, mll, 2)
+        h = hid_ref[:, :mll] if mll <= T else torch.cat([hid_ref, hid_ref.new_zeros(2, mll - T, hid_ref.size(2))], 1)
+        lg_ref, of_ref = O.head_forward(h, torch.from_numpy(lang), sd, hc)
+        assert (lg.cpu() - lg_ref).abs().max() <= 0.6 and (lg.cpu() - lg_ref).abs().mean() <= 0.08
+        assert (of.cpu() - of_ref).abs().max() <= 0.03
+    lg, _ = m(x, torch.from_numpy(lang), max_label_len=T)
+    assert torch.equal(lg, whole.logits)                            # no-op pad / truncate: the split path is the fused path
+
+
+def test_average_over_the_listed_languages_only():
+    """`lang_id=None` averages over the ids langs.txt lists (infer.py:147-156), which may be a subset of the embedding rows."""
+    cfg = tiny_whisper_config(enable_bilstm=False, num_languages=4)
+    m, labels, sd_np = _build(cfg, 5, seed=63)
+    wav = synth.make_batch(820, 2, 20000, seed=63)
+    x = torch.from_numpy(wav).cuda()
+    enc_name, arch = resolve_encoder_arch(cfg["model"])
+    sd = O.to_torch_state_dict(sd_np)
+    hc = synth.head_config(cfg["model"])
+
+    def ref(idlist):
+        lgs = [O.forward(torch.from_numpy(wav), torch.full((2,), i, dtype=torch.long), sd, enc_name, arch, hc)[0] for i in idlist]
+        return torch.stack(lgs).mean(0)
+
+    all4 = m.label(x, None, average_languages=True, want_logits=True).logits.cpu()
+    assert (all4 - ref([0, 1, 2, 3])).abs().max() <= 0.3
+    m.set_average_languages([3, 1])
+    sub = m.label(x, None, average_languages=True, want_logits=True).logits.cpu()
+    assert (sub - ref([3, 1])).abs().max() <= 0.3
+    assert (sub - all4).abs().max() > 0.05                         # it really is a different average
+    one = m.label(x, [3, 3], want_logits=True).logits
+    m.set_average_languages([3])
+    assert torch.equal(m.label(x, None, average_languages=True, want_logits=True).logits, one)
+    with pytest.raises(RuntimeError):
+        m.set_average_languages([4])
+
+
+def test_pipelined_loop_many_batches_equals_single_row_loop(tmp_path):
+    """Labeler(batch_size=2) over 7 files of mixed lengths -- one 44.1 kHz, one longer than 30 s, BiLSTM on -- so the loop runs
+    several batches through both streams / workspace slots, a partial last batch, reused pinned rows and the fall-back rows of
+    the native loader; every file must equal the reference's loop spelled out with single-row label() calls."""
+    from test_gpu_infer import _manual
+    d = tmp_path
+    cfg = tiny_whisper_config(enable_bilstm=True)
+    cfg["model"]["encoder_arch"]["max_positions"] = 1500
+    cfg["output"]["save_dir"] = str(d / "save")
+    cfg["postprocess"] = {"median_filter": 3, "merge_segments": "right", "confidence_threshold": 0.3}
+    os.makedirs(cfg["output"]["save_dir"])
+    labels = synth.make_labels(5)
+    (d / "save" / "phonemes.txt").write_text("\n".join(labels) + "\n")
+    (d / "save" / "langs.txt").write_text("en,0\nja,1\n")
+    with open(d / "config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, len(labels), seed=64).items()}
+    os.makedirs(d / "wavs")
+    secs = [7.0, 29.5, 1.2, 12.0, 3.3, 20.0]
+    paths = []
+    for i, s in enumerate(secs):
+        p = str(d / "wavs" / f"f{i}.wav")
+        A.write_wav(p, synth.make_clip(900 + i, int(16000 * s), seed=64) * (0.3 + 0.1 * i), 16000)
+        paths.append(p)
+    p = str(d / "wavs" / "hi.wav")
+    A.write_wav(p, A.resample(synth.make_clip(950, 16000 * 4, seed=64).astype(np.float64), 16000, 44100) * 0.9, 44100)
+    paths.insert(2, p)
+    p = str(d / "wavs" / "long.wav")
+    A.write_wav(p, synth.make_clip(951, 16000 * 47, seed=64) * 0.8, 16000)
+    paths.insert(5, p)
+    lab = I.Labeler(str(d / "config.yaml"), sd, device="cuda", batch_size=2)
+    for lang_id in (1, None):
+        got = lab.label_files(paths, lang_id=lang_id, confidence_threshold=0.3, verbose=False)
+        assert len(got) == len(paths)
+        for path, segs in zip(paths, got):
+            assert segs == _manual(lab, path, lang_id, 0.3), (path, lang_id)
+    lab.model.check(2, 480000, slot=0)
+    lab.model.check(2, 480000, slot=1)

@@ -7,7 +7,7 @@ import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libwfl_asr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class WflArch(C.Structure):
@@ -41,7 +41,12 @@ SIGNATURES = {
     "wfl_finalize": (_I, [_P]),
     "wfl_num_frames": (_I, [_P, _I]),
     "wfl_workspace_bytes": (_L, [_P, _I, _I]),
-    "wfl_forward": (_I, [_P, _P, _L, _P, _I, _I, _P, _I, _F, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
+    "wfl_device": (_I, [_P]),
+    "wfl_set_average_languages": (_I, [_P, _P, _I]),
+    "wfl_forward": (_I, [_P, _P, _L, _P, _I, _I, _P, _I, _F, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "wfl_encode": (_I, [_P, _P, _L, _P, _I, _I, _P, _L, _P, _P]),
+    "wfl_head_workspace_bytes": (_L, [_P, _I, _I]),
+    "wfl_head": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_check": (_I, [_P, _P, _L, _I, _I, _P]),
     "wfl_logmel": (_I, [_P, _P, _L, _P, _I, _I, _P, _P, _L, _P]),
     "wfl_op_gemm": (_I, [_P, _L, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _I, _P, _P, _L, _F, _I, _I, _I, _P]),

@@ -291,10 +291,9 @@ template <int HD, int QT, bool PREFETCH, bool BIAS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = (PREFETCH ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32));
   auto k = attn_kernel<HD, QT, PREFETCH, BIAS>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
-    attr_set = true;
   }
   const int qb = 4 * QT * 16;
   dim3 grid(((a.T + qb - 1) / qb) * a.heads * a.B);

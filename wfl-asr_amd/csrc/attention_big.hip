@@ -144,10 +144,9 @@ template <int HD, int KTL>
 static int launch_big(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = KTL * HD * 2 + KTL * (HD * 2 + 32);
   auto k = attn_big_kernel<HD, KTL>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
-    attr_set = true;
   }
   dim3 grid(((a.T + 63) / 64) * a.heads * a.B);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);

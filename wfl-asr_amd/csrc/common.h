@@ -104,6 +104,19 @@ static __device__ __forceinline__ float apply_act(float v) {
 static __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 static __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
+// hipFuncSetAttribute and small scratch allocations are per DEVICE: a launcher remembers, per kernel instantiation, on which
+// devices it has run (one process may hold models on several GPUs; normally one process drives one GPU).
+struct WflOncePerDevice {
+  unsigned mask = 0;
+  bool need() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if ((mask >> (d & 31)) & 1u) return false;
+    mask |= 1u << (d & 31);
+    return true;
+  }
+};
+
 // host-side launchers (one per .hip translation unit)
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s);
 // which kernel the last wfl_launch_gemm used (profiling labels): 1 gemm_stream<.,6>, 2 gemm256<.,6>, 3 gemm256<.,8>, 4 gemm_bf16 (128 tile), 5 gemm_stream<.,8>, 6 gemm_stream conv mode
@@ -112,4 +125,9 @@ bool wfl_gemm_stream_takes(const GemmArgs& a);   // gemm_stream.hip: would the s
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s);
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
                          long lead, int B, int P, int T, int C, hipStream_t s);
+// Plain fill / copy kernels.  The forward never uses hipMemsetAsync / hipMemcpyAsync: a memset NODE of 64 bytes or more captured
+// into a HIP graph writes garbage from its second replay on (ROCm 7.2, gfx950; tools/micro/graph_memset.py) -- the cause of the
+// graph-replay divergence seen in round 1 (the per-clip log-mel maximum was "cleared" to garbage).
+int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s);
+int wfl_launch_copy16(void* dst, const void* src, long bytes, hipStream_t s);   // bytes % 16 == 0, both 16-byte aligned
 int wfl_launch_zero_halo(bf16_t* buf, long ld_bytes, long lead, int B, int P, int T, long tail_rows, hipStream_t s);

@@ -314,10 +314,9 @@ template <int ACT, bool GLU, bool OUTF32>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
   auto k = gemm_bf16_kernel<ACT, GLU, OUTF32>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -2;
-    attr_set = true;
   }
   g_wfl_gemm_kernel_id = 4;
   hipLaunchKernelGGL(k, dim3(tiles), dim3(256), LDS_BYTES, s, a);

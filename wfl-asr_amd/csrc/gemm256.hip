@@ -324,10 +324,9 @@ static int launch256_mt(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / BN2);
   auto k = gemm256_kernel<ACT, GLU, OUTF32, MT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return -2;
-    attr_set = true;
   }
   g_wfl_gemm_kernel_id = MT == 6 ? 2 : 3;
   hipLaunchKernelGGL(k, dim3(tiles), dim3(512), LDS2, s, a);

@@ -482,10 +482,9 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
 #endif
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
   auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
-    attr_set = true;
   }
   g_wfl_gemm_kernel_id = CONV ? 6 : (MT == 6 ? 1 : 5);
   hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
@@ -540,12 +539,15 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
 // Returns 1 when this kernel does not take the launch (caller falls back to gemm256 / gemm).
 int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {
   if (!wfl_gemm_stream_takes(a)) return 1;
-  static void* trash = nullptr;
-  if (!trash) {
-    if (hipMalloc(&trash, 4096) != hipSuccess) return -2;
+  static void* trash[32] = {nullptr};        // per device: the scratch line must live where the kernel runs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 31;
+  if (!trash[dev]) {
+    if (hipMalloc(&trash[dev], 4096) != hipSuccess) return -2;
   }
   GemmArgs g = a;
-  g.trash = trash;
+  g.trash = trash[dev];
   if (g.ln_s) {
     if (g.stats_in) {
       switch (g.act) {

@@ -16,11 +16,14 @@ struct TagArgs {
   const float* w2;                   // [2][d]
   const float* b2;                   // [2]
   float* offsets;                    // [rows][2]
+  const unsigned* status_src;        // the forward's device-side error word -> *status_dst (both optional)
+  int* status_dst;
 };
 
 __global__ __launch_bounds__(256) void tag_decide_kernel(TagArgs p) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && p.status_dst) *p.status_dst = p.status_src ? (int)*p.status_src : 0;
   if (r >= p.rows) return;
   if (p.logits) {
     const float* lp = p.logits + r * p.ldl;

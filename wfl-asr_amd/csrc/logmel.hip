@@ -203,12 +203,11 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restr
 int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s) {
   if (a.n_frames * HOP != a.n_samples || a.n_mels <= 0 || a.B <= 0) return -1;
   constexpr int lds = (((SEG_LDS + 3) & ~3) + FT * PPITCH) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)logmel_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
-    attr_set = true;
   }
-  if (hipMemsetAsync(a.clipmax, 0, sizeof(unsigned) * a.B, s) != hipSuccess) return -3;
+  if (wfl_launch_fill_i32((int*)a.clipmax, a.B, 0, s)) return -3;          // (a kernel, not a memset node: common.h)
   dim3 grid((a.n_frames + FT - 1) / FT, a.B);
   hipLaunchKernelGGL(logmel_power_kernel, grid, dim3(256), lds, s, a);
   const long total = (long)a.B * a.n_frames * a.n_mels;

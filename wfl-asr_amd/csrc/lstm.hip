@@ -217,8 +217,8 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
   const long hx_bytes = 2L * groups * 2 * 16 * a.H * 2;
   a.hx = (bf16_t*)exchange;
   a.counters = (unsigned*)((char*)exchange + hx_bytes);
-  a.error = a.counters + 2 * groups;
-  if (hipMemsetAsync(a.counters, 0, (2 * groups + 1) * sizeof(unsigned), s) != hipSuccess) return -3;
+  if (!a.error) return -1;                 // the forward's error word (ORed into, never cleared here)
+  if (wfl_launch_fill_i32((int*)a.counters, 2 * groups, 0, s)) return -3;   // (a kernel, not a memset node: common.h)
   const int maxt = (a.U / 4 + 3) / 4;
   switch (a.H) {
     case 32: return maxt <= 2 ? launch_lstm_t<32, 2>(a, groups, s) : -4;

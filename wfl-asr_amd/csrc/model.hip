@@ -39,8 +39,11 @@ struct TagArgs {
   const float* w2;
   const float* b2;
   float* offsets;
+  const unsigned* status_src;   // the forward's device-side error word -> *status_dst (both optional)
+  int* status_dst;
 };
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
+int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s);
 
 struct LstmArgs {
   const float* gx; long ldgx;
@@ -75,7 +78,6 @@ int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, con
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
-int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s);
 struct ZeroMulti {
   int n;
   char* buf[10];
@@ -84,6 +86,7 @@ struct ZeroMulti {
   int P[10], T[10];
   long tail_rows[10];
   int B;
+  unsigned* err_word;   // the forward's device-side error word, cleared here (first kernel of every forward); may be null
 };
 int wfl_launch_zero_halo_multi(const ZeroMulti& z, hipStream_t s);
 int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s);
@@ -144,6 +147,8 @@ struct GemmProf {
 struct wfl_model {
   wfl_arch a{};
   bool finalized = false;
+  int device = -1;                   // HIP device the weights live on (current device at wfl_finalize)
+  std::vector<int> avg_langs;        // WFL_LANG_AVERAGE: the ids averaged over (default: all)
   std::map<std::string, HostTensor> host;
   std::vector<void*> dev_allocs;
   // geometry
@@ -705,6 +710,7 @@ int32_t wfl_finalize(wfl_model* m) {
   if (!m) return fail(-1, "wfl_finalize: null model");
   if (m->finalized) return fail(-1, "wfl_finalize: already finalized");
   Packer P{m};
+  if (hipGetDevice(&m->device) != hipSuccess) return fail(-10, "wfl_finalize: hipGetDevice failed");
   if (m->a.encoder_type == WFL_ENC_WHISPER) finalize_whisper(m, P);
   else finalize_wavlm(m, P);
   if (P.err.empty()) finalize_head(m, P);
@@ -712,7 +718,31 @@ int32_t wfl_finalize(wfl_model* m) {
   for (auto& kv : m->host)
     if (!P.used.count(kv.first)) return fail(-2, "wfl_finalize: unexpected key in state_dict: " + kv.first);
   m->host.clear();
+  m->avg_langs.clear();
+  for (int i = 0; i < m->a.num_languages; ++i) m->avg_langs.push_back(i);
   m->finalized = true;
+  return 0;
+}
+
+int32_t wfl_device(const wfl_model* m) { return m ? m->device : -1; }
+
+int32_t wfl_set_average_languages(wfl_model* m, const int32_t* ids_host, int32_t n) {
+  if (!m || !m->finalized) return fail(-1, "wfl_set_average_languages: model not finalized");
+  if (!ids_host || n <= 0) return fail(-1, "wfl_set_average_languages: empty id list");
+  for (int i = 0; i < n; ++i)
+    if (ids_host[i] < 0 || ids_host[i] >= m->a.num_languages) return fail(-1, "wfl_set_average_languages: id out of range");
+  m->avg_langs.assign(ids_host, ids_host + n);
+  return 0;
+}
+
+// Every entry point that touches the device: the model's device must be the current one (a handle on GPU 1 driven with GPU 0
+// current would dereference GPU-1 weight pointers from GPU-0 kernels).
+static int check_device(const wfl_model* m, const char* who) {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) return fail(-10, std::string(who) + ": hipGetDevice failed");
+  if (d != m->device)
+    return fail(-11, std::string(who) + ": the model lives on HIP device " + std::to_string(m->device) + " but device " +
+                         std::to_string(d) + " is current (call hipSetDevice / torch.cuda.set_device first)");
   return 0;
 }
 
@@ -729,7 +759,7 @@ struct Plan {
   long Rl[8];
   // byte offsets
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
-  long FA, FB, XG, gate, rtab, wstats, cstats, total;
+  long FA, FB, XG, gate, rtab, wstats, cstats, err, total;
 };
 
 static int wavlm_frames(const wfl_arch& a, int L) {
@@ -741,12 +771,13 @@ static int wavlm_frames(const wfl_arch& a, int L) {
   return (int)t;
 }
 
-static Plan make_plan(const wfl_model* m, int B, int L) {
+// T_frames > 0: a head-only plan over that many frames per clip (wfl_head): no encoder-side buffers.
+static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   const wfl_arch& a = m->a;
   const bool whisper = a.encoder_type == WFL_ENC_WHISPER;
   Plan p{};
   p.B = B; p.L = L;
-  p.T = whisper ? a.max_positions : wavlm_frames(a, L);
+  p.T = T_frames > 0 ? T_frames : (whisper ? a.max_positions : wavlm_frames(a, L));
   p.P = (int)round_up(p.T + m->halo, 8);
   p.lead = m->halo;
   p.tail = 256;
@@ -757,7 +788,8 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
   p.ffw = std::max(a.enc_ffn, a.d_model * std::max(a.conformer_ff_expansion, 1));
   long off = 0;
   auto take = [&](long bytes) { long o = off; off = round_up(off + bytes, 256); return o; };
-  if (whisper) {
+  if (T_frames > 0) {
+  } else if (whisper) {
     p.mel = take(p.R2 * a.n_mels * 2 + 1024);
     p.c1 = take(p.R2 * p.d * 2);
     p.raw = take((long)B * p.T2 * a.n_mels * 4);
@@ -798,6 +830,7 @@ static Plan make_plan(const wfl_model* m, int B, int L) {
     p.gx = take(p.R * 4L * p.d * 4);                       // fp32 [rows][8H]
     p.lstm_x = take(wfl_lstm_exchange_bytes(p.d / 2, B));
   }
+  p.err = take(256);                                     // the forward's device-side error word
   p.total = off;
   return p;
 }
@@ -962,43 +995,41 @@ int32_t wfl_logmel(wfl_model* m, const float* wav, int64_t ldw, const int32_t* l
   if (!m || !m->finalized) return fail(-1, "wfl_logmel: model not finalized");
   if (m->a.encoder_type != WFL_ENC_WHISPER) return fail(-1, "wfl_logmel: not a Whisper model");
   if (B <= 0 || L < 0 || ldw < L) return fail(-1, "wfl_logmel: bad shape");
+  if (int r = check_device(m, "wfl_logmel")) return r;
   const Plan p = make_plan(m, B, L);
   if (workspace_bytes < p.total) return fail(-1, "wfl_logmel: workspace too small");
   const int r = run_logmel(m, p, (char*)workspace, wav, ldw, lens, out, (hipStream_t)stream);
   return r ? fail(r, "logmel launch failed") : 0;
 }
 
-int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,
-                    const int32_t* lang_id, int32_t lang_mode, float threshold, void* workspace, int64_t workspace_bytes,
-                    int32_t* ids, int32_t* argmax, float* maxprob, float* offsets, float* logits, float* hidden,
-                    void* stream) {
-  if (!m || !m->finalized) return fail(-1, "wfl_forward: model not finalized");
-  if (!wav || B <= 0 || L <= 0 || ldw < L) return fail(-1, "wfl_forward: bad input shape");
-  if (!ids || !maxprob || !offsets) return fail(-1, "wfl_forward: ids, maxprob and offsets are required");
-  if (lang_mode == WFL_LANG_IDS && !lang_id) return fail(-1, "wfl_forward: lang_id missing");
-  if (lang_mode == WFL_LANG_AVERAGE && m->a.num_languages <= 0) return fail(-1, "wfl_forward: no languages to average");
-  const wfl_arch& a = m->a;
-  Runner R{m, make_plan(m, B, L), (char*)workspace, (hipStream_t)stream};
+// Halo rows of the buffers every stage shares (cheap; keeps the layout invariant independent of the workspace's history) and
+// the forward's error word.
+static int begin_forward(Runner& R, bool with_encoder) {
+  const wfl_arch& a = R.m->a;
   const Plan& p = R.p;
-  if (workspace_bytes < p.total) return fail(-1, "wfl_forward: workspace too small");
   const int d = p.d;
-  const long Mrows = (long)B * p.P;
-  bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *FF = R.buf(p.FF);
-
-  if (p.T <= 0) return fail(-1, "wfl_forward: clip too short for the encoder");
-  // halos of every frame-row buffer (cheap; keeps the layout invariant independent of the workspace's history)
+  R.zm.err_word = (unsigned*)(R.ws + p.err);      // cleared by the halo kernel (a kernel, not a memset node: graph replay)
   R.zero_add(p.X, d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.Y, d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.ATT, d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.QK, 3 * d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
-  if (a.encoder_type == WFL_ENC_WHISPER) {
+  if (with_encoder && a.encoder_type == WFL_ENC_WHISPER) {
     R.zero_add(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
     R.zero_add(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
   }
   R.zero_flush();
-  if (R.rc) return R.rc;
+  return R.rc;
+}
 
+// Feature extractor + encoder (model.py:149-161): leaves the encoder output in the Y rows.
+static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* lens) {
+  wfl_model* m = R.m;
+  const wfl_arch& a = m->a;
+  const Plan& p = R.p;
+  const int B = p.B, L = p.L, d = p.d;
+  const long Mrows = (long)B * p.P;
+  bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *FF = R.buf(p.FF);
   if (a.encoder_type == WFL_ENC_WHISPER) {
     // ---- Whisper encoder (HF modeling_whisper.py:618-642)
     const int r = run_logmel(m, p, R.ws, wav, ldw, lens, nullptr, R.s);
@@ -1112,22 +1143,28 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     if (stable) { R.ln(H, S, m->wenc_ln); std::swap(H, S); }
     if (H != Y && !R.rc) {                             // the head expects the encoder output in Y
       R.stats_for = nullptr;
-      HIPCHK(hipMemcpyAsync(Y, H, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
+      if (wfl_launch_copy16(Y, H, p.R * d * 2, R.s)) return fail(-3, "copy launch failed");
     }
   }
-  if (R.rc) return R.rc;
-  if (hidden) {
-    const int r = wfl_launch_rows_to_f32(Y, d, p.lead, B, p.P, p.T, d, hidden, R.s);
-    if (r) return fail(r, "rows_to_f32 launch failed");
-  }
+  return R.rc;
+}
 
+// Head (model.py:176-194) + tag decision on the encoder output in the Y rows.
+static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float threshold, int32_t* ids, int32_t* argmax,
+                    float* maxprob, float* offsets, float* logits, int32_t* status) {
+  wfl_model* m = R.m;
+  const wfl_arch& a = m->a;
+  const Plan& p = R.p;
+  const int B = p.B, d = p.d;
+  const long Mrows = (long)B * p.P;
+  bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *FF = R.buf(p.FF);
   // ---- head (model.py:176-194); with WFL_LANG_AVERAGE it runs once per language on the same encoder output
-  const int n_pass = lang_mode == WFL_LANG_AVERAGE ? a.num_languages : 1;
+  const int n_pass = lang_mode == WFL_LANG_AVERAGE ? (int)m->avg_langs.size() : 1;
   float* lg = logits ? logits : (float*)(R.ws + p.logits);
   bf16_t* ENC = Y;
   // the head needs Y as scratch: keep the encoder output in ATT when more than one pass reads it
   if (n_pass > 1) {
-    HIPCHK(hipMemcpyAsync(R.buf(p.enc2), Y, (size_t)p.R * d * 2, hipMemcpyDeviceToDevice, R.s));
+    if (wfl_launch_copy16(R.buf(p.enc2), Y, p.R * d * 2, R.s)) return fail(-3, "copy launch failed");
     ENC = R.buf(p.enc2);
   }
   int* lang_dev = nullptr;
@@ -1139,9 +1176,9 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     } else {
       const int* idx = lang_id;
       if (lang_mode == WFL_LANG_AVERAGE) {
-        // clip_idx = pass for every clip: reuse the clipmax slot region (B ints) as a constant index vector
+        // clip_idx = this pass's language id for every clip: reuse the clipmax slot region (B ints) as a constant index vector
         lang_dev = (int*)(R.ws + p.clipmax);
-        const int fr = wfl_launch_fill_i32(lang_dev, B, pass, R.s);
+        const int fr = wfl_launch_fill_i32(lang_dev, B, m->avg_langs[pass], R.s);
         if (fr) return fail(fr, "fill launch failed");
         idx = lang_dev;
       }
@@ -1159,6 +1196,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
         LstmArgs la{};
         la.gx = GX; la.ldgx = 8 * Hh; la.whh = m->lstm_whh[layer]; la.out = S; la.ldo = d; la.lead = p.lead;
         la.B = B; la.T = p.T; la.P = p.P; la.H = Hh; la.U = m->lstm_U;
+        la.error = (unsigned*)(R.ws + p.err);
         R.stats_for = nullptr;
         const int lr = wfl_launch_lstm(la, R.ws + p.lstm_x, R.s);
         if (lr) return fail(lr, lr == -5 ? "BiLSTM: batch too large for one resident launch (max 256 / (2 * H/U) groups of 16 clips)"
@@ -1206,6 +1244,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
     t.hid = S; t.ldh = d; t.lead = p.lead; t.P = p.P; t.T = p.T; t.d = d; t.w2 = m->off_w2; t.b2 = m->off_b2;
     if (n_pass == 1) {
       t.logits = lg; t.ldl = a.num_classes; t.offsets = offsets;
+      t.status_src = (const unsigned*)(R.ws + p.err); t.status_dst = status;
       const int r = wfl_launch_tag_decide(t, R.s);
       if (r) return fail(r, "tag_decide launch failed");
     } else {
@@ -1228,6 +1267,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
         TagArgs f{};
         f.logits = lg; f.ldl = a.num_classes; f.rows = B * p.T; f.C = a.num_classes; f.threshold = threshold;
         f.o_id = a.o_id; f.ids = ids; f.argmax = argmax; f.maxprob = maxprob;
+        f.status_src = (const unsigned*)(R.ws + p.err); f.status_dst = status;
         r = wfl_launch_tag_decide(f, R.s);
         if (r) return fail(r, "tag_decide launch failed");
       }
@@ -1236,17 +1276,83 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
   return R.rc;
 }
 
+static int check_forward_args(const wfl_model* m, const char* who, int32_t B, const int32_t* lang_id, int32_t lang_mode,
+                              const int32_t* ids, const float* maxprob, const float* offsets) {
+  if (!ids || !maxprob || !offsets) return fail(-1, std::string(who) + ": ids, maxprob and offsets are required");
+  if (B <= 0) return fail(-1, std::string(who) + ": bad batch size");
+  if (lang_mode == WFL_LANG_IDS && !lang_id) return fail(-1, std::string(who) + ": lang_id missing");
+  if (lang_mode == WFL_LANG_AVERAGE && m->avg_langs.empty()) return fail(-1, std::string(who) + ": no languages to average");
+  if (lang_mode < WFL_LANG_NONE || lang_mode > WFL_LANG_AVERAGE) return fail(-1, std::string(who) + ": bad lang_mode");
+  return 0;
+}
+
+int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,
+                    const int32_t* lang_id, int32_t lang_mode, float threshold, void* workspace, int64_t workspace_bytes,
+                    int32_t* ids, int32_t* argmax, float* maxprob, float* offsets, float* logits, float* hidden,
+                    int32_t* status, void* stream) {
+  if (!m || !m->finalized) return fail(-1, "wfl_forward: model not finalized");
+  if (!wav || B <= 0 || L <= 0 || ldw < L) return fail(-1, "wfl_forward: bad input shape");
+  if (int r = check_forward_args(m, "wfl_forward", B, lang_id, lang_mode, ids, maxprob, offsets)) return r;
+  if (int r = check_device(m, "wfl_forward")) return r;
+  Runner R{m, make_plan(m, B, L), (char*)workspace, (hipStream_t)stream};
+  const Plan& p = R.p;
+  if (!workspace || workspace_bytes < p.total) return fail(-1, "wfl_forward: workspace too small");
+  if (p.T <= 0) return fail(-1, "wfl_forward: clip too short for the encoder");
+  if (int r = begin_forward(R, true)) return r;
+  if (int r = run_encoder(R, wav, ldw, lens)) return r;
+  if (hidden) {
+    const int r = wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, B, p.P, p.T, p.d, hidden, R.s);
+    if (r) return fail(r, "rows_to_f32 launch failed");
+  }
+  return run_head(R, lang_id, lang_mode, threshold, ids, argmax, maxprob, offsets, logits, status);
+}
+
+int32_t wfl_encode(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L, void* workspace,
+                   int64_t workspace_bytes, float* hidden, void* stream) {
+  if (!m || !m->finalized) return fail(-1, "wfl_encode: model not finalized");
+  if (!wav || !hidden || B <= 0 || L <= 0 || ldw < L) return fail(-1, "wfl_encode: bad argument");
+  if (int r = check_device(m, "wfl_encode")) return r;
+  Runner R{m, make_plan(m, B, L), (char*)workspace, (hipStream_t)stream};
+  const Plan& p = R.p;
+  if (!workspace || workspace_bytes < p.total) return fail(-1, "wfl_encode: workspace too small");
+  if (p.T <= 0) return fail(-1, "wfl_encode: clip too short for the encoder");
+  if (int r = begin_forward(R, true)) return r;
+  if (int r = run_encoder(R, wav, ldw, lens)) return r;
+  const int r = wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, B, p.P, p.T, p.d, hidden, R.s);
+  return r ? fail(r, "rows_to_f32 launch failed") : 0;
+}
+
+int64_t wfl_head_workspace_bytes(const wfl_model* m, int32_t B, int32_t T) {
+  if (!m || B <= 0 || T <= 0) return -1;
+  return make_plan(m, B, 0, T).total;
+}
+
+int32_t wfl_head(wfl_model* m, const float* hidden, int32_t B, int32_t T, const int32_t* lang_id, int32_t lang_mode,
+                 float threshold, void* workspace, int64_t workspace_bytes, int32_t* ids, int32_t* argmax, float* maxprob,
+                 float* offsets, float* logits, int32_t* status, void* stream) {
+  if (!m || !m->finalized) return fail(-1, "wfl_head: model not finalized");
+  if (!hidden || T <= 0) return fail(-1, "wfl_head: bad argument");
+  if (int r = check_forward_args(m, "wfl_head", B, lang_id, lang_mode, ids, maxprob, offsets)) return r;
+  if (int r = check_device(m, "wfl_head")) return r;
+  Runner R{m, make_plan(m, B, 0, T), (char*)workspace, (hipStream_t)stream};
+  const Plan& p = R.p;
+  if (!workspace || workspace_bytes < p.total) return fail(-1, "wfl_head: workspace too small");
+  if (int r = begin_forward(R, false)) return r;
+  const int r = wfl_launch_f32_to_rows(hidden, R.buf(p.Y), p.d, p.lead, B, p.P, p.T, p.d, R.s);
+  if (r) return fail(r, "f32_to_rows launch failed");
+  return run_head(R, lang_id, lang_mode, threshold, ids, argmax, maxprob, offsets, logits, status);
+}
+
 int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_t B, int32_t L, void* stream) {
   if (!m || !m->finalized || !workspace) return fail(-1, "wfl_check: bad argument");
+  if (int r = check_device(m, "wfl_check")) return r;
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  if (!m->a.enable_bilstm) return 0;
   const Plan p = make_plan(m, B, L);
   if (workspace_bytes < p.total) return fail(-1, "wfl_check: workspace too small");
-  const long groups = (B + 15) / 16;
-  const long hx_bytes = 2L * groups * 2 * 16 * (m->a.d_model / 2) * 2;
   unsigned err = 0;
-  HIPCHK(hipMemcpy(&err, (char*)workspace + p.lstm_x + hx_bytes + 2 * groups * sizeof(unsigned), sizeof(unsigned), hipMemcpyDeviceToHost));
-  if (err) return fail(-20, "BiLSTM recurrence: an inter-workgroup wait timed out (results of the last forward are invalid)");
+  HIPCHK(hipMemcpy(&err, (char*)workspace + p.err, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (err & 1u) return fail(-20, "BiLSTM recurrence: an inter-workgroup wait timed out (results of the last forward are invalid)");
+  if (err) return fail(-21, "device-side error word " + std::to_string(err));
   return 0;
 }
 

@@ -145,13 +145,49 @@ int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, i
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// compact fp32 [B][T][C] -> bf16 frame rows (wfl_head: the caller's encoder output)
+__global__ __launch_bounds__(256) void f32_to_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ x, long ldx, long lead,
+                                                          int B, int P, int T, int C) {
+  const long total = (long)B * T * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    x[(lead + (long)b * P + t) * ldx + c] = f2bf(in[i]);
+  }
+}
+
+int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s) {
+  const long total = (long)B * T * C;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(f32_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, x, ldx, lead, B, P, T, C);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 __global__ void fill_i32_kernel(int* dst, long n, int value) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = value;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = value;
 }
 
 int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s) {
-  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, value);
+  if (n <= 0) return 0;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, n, value);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+int wfl_launch_copy16(void* dst, const void* src, long bytes, hipStream_t s) {
+  if (bytes <= 0) return 0;
+  if (bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16) return -1;
+  const long n = bytes / 16;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -164,10 +200,12 @@ struct ZeroMulti {
   int P[10], T[10];
   long tail_rows[10];
   int B;
+  unsigned* err_word;   // the forward's device-side error word, cleared here (first kernel of every forward); may be null
 };
 
 __global__ __launch_bounds__(256) void zero_halo_multi_kernel(ZeroMulti z) {
   const int k = blockIdx.y;
+  if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0 && z.err_word) *z.err_word = 0u;
   if (k >= z.n) return;
   char* buf = z.buf[k];
   const long ld_bytes = z.ld_bytes[k], lead = z.lead[k], tail_rows = z.tail_rows[k];

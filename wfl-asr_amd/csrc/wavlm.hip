@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args p) {
 }
 
 int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s) {
-  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s) != hipSuccess) return -3;
+  if (wfl_launch_fill_i32((int*)stats, 4L * B, 0, s)) return -3;           // (a kernel, not a memset node: common.h)
   int blocks = (L + 256 * 16 - 1) / (256 * 16);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(wav_stats_kernel, dim3(blocks, B), dim3(256), 0, s, wav, ldw, L, stats);
@@ -162,7 +162,7 @@ int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats
 int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s) {
   if (a.C % 8 || a.C > 512 || a.T0 <= 0) return -1;
   if (group_norm) {
-    if (hipMemsetAsync(a.cstats, 0, sizeof(double) * 2 * a.B * a.C, s) != hipSuccess) return -3;
+    if (wfl_launch_fill_i32((int*)a.cstats, 4L * a.B * a.C, 0, s)) return -3;
     dim3 grid((a.T0 + C0_TT - 1) / C0_TT, a.B);
     hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), 0, s, a);

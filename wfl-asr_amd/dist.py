@@ -4,6 +4,8 @@ The reference is single-process; every clip / 30 s ch
 independent (§8e), so the build deals work items to ranks by cost and, at the end of a batch, moves the per-clip tag
 tensors (~24 KB per 30 s clip) to rank 0 with ONE collective: `ids | maxprob | offsets` are packed bit-for-bit
 into a single int32 [n, T, 4] payload and gathered over RCCL (backend "nccl" on ROCm; gloo in the CPU tests).
+The product loop does not even pack: `TagBatch.packed` (tagger.py) already is one contiguous int32 blob
+`ids [n*T] | maxprob bits [n*T] | offsets bits [n*T*2] | status word`, which `gather_packed` moves as it stands.
 """
 from __future__ import annotations
 
@@ -72,3 +74,31 @@ def gather_tags(ids, maxprob, offsets, dst: int = 0, counts=None, group=None):
         return ids, maxprob, offsets
     full = torch.cat([b[:c] for b, c in zip(bufs, counts)])
     return unpack_tags(full)
+
+
+def split_packed(blob: torch.Tensor, n: int, T: int):
+    """Views into one `TagBatch.packed` blob (4*n*T + 1 int32 words) -> (ids [n,T] i32, maxprob [n,T] f32,
+    offsets [n,T,2] f32, status word [1] i32).  No copies."""
+    nt = n * T
+    if blob.numel() != 4 * nt + 1:
+        raise ValueError("blob does not hold n x T packed tags")
+    return (blob[0:nt].view(n, T), blob[nt:2 * nt].view(torch.float32).view(n, T),
+            blob[2 * nt:4 * nt].view(torch.float32).view(n, T, 2), blob[4 * nt:4 * nt + 1])
+
+
+def gather_packed(blob: torch.Tensor, dst: int = 0, out=None, group=None):
+    """ONE collective for a step's tags: every rank's contiguous `TagBatch.packed` blob (equal sizes: ranks label equal
+    batches; a short last batch is padded by its owner) lands on `dst` as rows of `out` ([world, words] int32, allocated
+    here when None).  Returns `out` on `dst` (row r = rank r's blob, split with `split_packed`), None elsewhere; with one
+    rank, the blob itself as a [1, words] view."""
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return blob.view(1, -1)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank != dst:
+        dist.gather(blob, None, dst=dst, group=group)
+        return None
+    if out is None:
+        out = torch.empty(world, blob.numel(), dtype=blob.dtype, device=blob.device)
+    dist.gather(blob, [out[r] for r in range(world)], dst=dst, group=group)
+    return out

@@ -24,7 +24,7 @@ import yaml
 from . import audio as A
 from . import native_post as npost
 from . import postprocess as pp
-from .tagger import BIOPhonemeTagger
+from .tagger import BIOPhonemeTagger, raise_on_status
 
 frame_duration = pp.FRAME_DURATION
 MAX_SEGMENT_DURATION = pp.MAX_SEGMENT_DURATION
@@ -36,17 +36,28 @@ def load_config(config_path="config.yaml"):
         return yaml.safe_load(f)
 
 
+def pick_device(device="cuda") -> torch.device:
+    """The HIP device this process labels on.  An explicit index wins; a bare "cuda" means cuda:LOCAL_RANK under a
+    one-process-per-GPU launcher (torchrun sets LOCAL_RANK and WORLD_SIZE) and the current device otherwise."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("this build labels on MI355X only: --device must be cuda[:N] (there is no CPU path)")
+    if dev.index is not None:
+        return dev
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "LOCAL_RANK" in os.environ:
+        return torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 class Labeler:
     """Model + sidecar files loaded once; `label_files` runs the batched hot loop."""
 
     def __init__(self, config_path, checkpoint_path, device="cuda", batch_size=16, use_graph=False):
         self.config = load_config(config_path) if isinstance(config_path, (str, os.PathLike)) else config_path
-        dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("this build labels on MI355X only: --device must be cuda[:N] (there is no CPU path)")
-        if not torch.cuda.is_available():
+        if torch.device(device).type == "cuda" and not torch.cuda.is_available():
             raise RuntimeError("no ROCm device visible")
-        self.device = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = pick_device(device)
+        torch.cuda.set_device(self.device)       # weights, workspaces, streams and pinned staging all belong to this device
         self.sr = int(self.config["data"]["sample_rate"])
         if self.sr != 16000:
             raise ValueError("both encoders are 16 kHz models (config data.sample_rate must be 16000)")
@@ -56,13 +67,16 @@ class Labeler:
         self.lang2id = pp.load_langs(langs_path) if os.path.exists(langs_path) else {}
         mm_path = os.path.join(save_dir, "phoneme_merge_map.json")
         self.merge_map = pp.load_phoneme_merge_map(mm_path) if os.path.exists(mm_path) else None
-        self.model = BIOPhonemeTagger(self.config, self.labels)
+        self.model = BIOPhonemeTagger(self.config, self.labels, device=self.device)
         if isinstance(checkpoint_path, dict):
             state_dict = checkpoint_path
         else:
             state_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         self.model.load_state_dict(state_dict)
         self.model.to(self.device).eval()
+        if self.lang2id:
+            # `lang_id=None` averages over the ids langs.txt lists, in file order (infer.py:147-156, 266-276)
+            self.model.set_average_languages(list(self.lang2id.values()))
         self.batch_size = int(batch_size)
         self.use_graph = bool(use_graph)
         self._pinned = None
@@ -103,7 +117,7 @@ class Labeler:
         T = self.model.num_frames(L)
         if self._pinned is None:
             self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(2)]
-            self._pinned_out = [torch.empty(Bs * T * 4, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pinned_out = [torch.empty(Bs * T * 4 + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         use_pipe = not self.use_graph
         pending = [None, None]
@@ -116,6 +130,7 @@ class Labeler:
             ev.synchronize()
             blob = self._pinned_out[slot].numpy()
             nn = Bs * T
+            raise_on_status(int(blob[4 * nn]))             # the forward's device-side error word rides behind the tags
             take(k, n, blob[0:nn].reshape(Bs, T), blob[2 * nn:4 * nn].view(np.float32).reshape(Bs, T, 2))
             pending[slot] = None
 
@@ -149,6 +164,7 @@ class Labeler:
                 res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold,
                                        average_languages=lang_id is None)
                 ids, offs = res.ids.cpu().numpy(), res.offsets.cpu().numpy()
+                raise_on_status(int(res.status.item()))
                 for j, i in enumerate(sel):
                     out[i] = (ids[j], offs[j])
         return out

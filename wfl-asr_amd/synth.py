@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .archs import WhisperArch, WavLMArch, resolve_encoder_arch
+from .archs import WhisperArch, WavLMArch, head_config, resolve_encoder_arch  # noqa: F401 (head_config re-exported)
 
 _M64 = (1 << 64) - 1
 
@@ -51,23 +51,6 @@ def _sym(name, shape, amp, seed):
 # --------------------------------------------------------------------------------------
 # state-dict specification (names/shapes exactly as the reference's strict load expects)
 # --------------------------------------------------------------------------------------
-
-def head_config(model_cfg: dict) -> dict:
-    """The `.get()` defaults scattered through /root/reference/model.py:61-66, 96, 108, 118-123."""
-    return dict(
-        enable_bilstm=bool(model_cfg.get("enable_bilstm", True)),
-        bilstm_num_layer=int(model_cfg.get("bilstm_num_layer", 1)),
-        enable_dilated_conv=bool(model_cfg.get("enable_dilated_conv", True)),
-        dilated_conv_depth=int(model_cfg.get("dilated_conv_depth", 2)),
-        dilated_conv_kernel=int(model_cfg.get("dilated_conv_kernel", 3)),
-        num_conformer_layers=int(model_cfg.get("num_conformer_layers", 2)),
-        conformer_heads=int(model_cfg.get("conformer_heads", 4)),
-        conformer_ff_expansion=int(model_cfg.get("conformer_ff_expansion", 4)),
-        conformer_kernel_size=int(model_cfg.get("conformer_kernel_size", 31)),
-        lang_emb_dim=int(model_cfg.get("lang_emb_dim", 64)),
-        num_languages=int(model_cfg["num_languages"]),
-    )
-
 
 def _lin(spec, prefix, out_f, in_f, bias=True, gain=1.0):
     spec[prefix + ".weight"] = ((out_f, in_f), "w", in_f, gain)

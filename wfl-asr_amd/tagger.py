@@ -13,8 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .archs import WhisperArch, resolve_encoder_arch
-from .synth import head_config
+from .archs import WhisperArch, head_config, resolve_encoder_arch
 
 LANG_NONE, LANG_IDS, LANG_AVERAGE = 0, 1, 2
 
@@ -23,27 +22,47 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _resolve_device(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.WflError("this build runs on MI355X only (device must be cuda[:N]); there is no CPU path")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 class TagBatch:
     """Decisions for a batch: ids/argmax [B,T] int32, maxprob [B,T], offsets [B,T,2], optional logits/hidden."""
 
     def __init__(self, ids, argmax, maxprob, offsets, logits=None, hidden=None):
         self.ids, self.argmax, self.maxprob, self.offsets = ids, argmax, maxprob, offsets
         self.logits, self.hidden = logits, hidden
-        self.packed = None      # int32 view over ids | maxprob | offsets (one contiguous D2H copy)
+        self.packed = None      # int32 view over ids | maxprob | offsets | status word (one contiguous D2H copy)
+        self.status = None      # int32 [1]: device-side error bits of this forward (0 = ok), the last word of `packed`
+
+
+def raise_on_status(word: int):
+    """`word` = TagBatch.status after the forward finished (include/wfl_asr.h: bit 0 = BiLSTM hand-off time-out)."""
+    if word:
+        raise _lib.WflError(f"the forward reported a device-side error (status {int(word):#x}"
+                            + (": a BiLSTM inter-workgroup wait timed out" if int(word) & 1 else "") + "); its tags are invalid")
 
 
 class BIOPhonemeTagger:
-    def __init__(self, config: dict, label_list):
+    def __init__(self, config: dict, label_list, device=None):
+        """device: the HIP device the weights will live on (default: the current one when load_state_dict runs).  Every
+        kernel launch of this object happens with that device current."""
         self.config = config
+        self.device = _resolve_device(device) if device is not None else None
         self.encoder_type, self.arch = resolve_encoder_arch(config["model"])
-        self.head = head_config(config["model"])
+        self.head_cfg = head_config(config["model"])
         self.label_list = list(label_list)
         self.label2id = {label: i for i, label in enumerate(self.label_list)}
         self.id2label = {i: label for label, i in self.label2id.items()}
         if "O" not in self.label2id:
             raise ValueError('label_list has no "O" tag')
         self.hidden_size = self.arch.d_model
-        self.num_languages = self.head["num_languages"]
+        self.num_languages = self.head_cfg["num_languages"]
         self._lib = _lib.load()
         self._handle = C.c_void_p(0)
         self._ready = False
@@ -69,7 +88,7 @@ class BIOPhonemeTagger:
             a.wavlm_pos_conv_kernel, a.wavlm_pos_conv_groups = w.pos_conv_kernel, w.pos_conv_groups
             a.wavlm_num_buckets, a.wavlm_max_distance = w.num_buckets, w.max_distance
             a.wavlm_do_normalize = int(w.do_normalize)
-        h = self.head
+        h = self.head_cfg
         a.num_classes, a.o_id = len(self.label_list), self.label2id["O"]
         a.num_languages, a.lang_emb_dim = h["num_languages"], h["lang_emb_dim"]
         a.enable_bilstm, a.bilstm_layers = int(h["enable_bilstm"]), h["bilstm_num_layer"]
@@ -92,15 +111,25 @@ class BIOPhonemeTagger:
             shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
             _lib.check(self._lib.wfl_load_tensor(self._handle, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim),
                        f"wfl_load_tensor({name})")
-        _lib.check(self._lib.wfl_finalize(self._handle), "load_state_dict")
+        if self.device is None:
+            self.device = _resolve_device("cuda")
+        with torch.cuda.device(self.device):         # wfl_finalize uploads to the CURRENT device
+            _lib.check(self._lib.wfl_finalize(self._handle), "load_state_dict")
         self._ready = True
         return self
 
     def to(self, device):
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.WflError("this build runs on MI355X only (device must be cuda[:N]); there is no CPU path")
+        dev = _resolve_device(device)
+        if self._ready and dev != self.device:
+            raise _lib.WflError(f"the weights were uploaded to {self.device}; build the tagger with device={dev} (or call "
+                                ".to() before load_state_dict) instead of moving it")
+        self.device = dev
         return self
+
+    def set_average_languages(self, ids):
+        """The ids `lang_id=None` averages over: the reference loops over langs.txt (infer.py:147, 268)."""
+        arr = (C.c_int32 * len(ids))(*[int(i) for i in ids])
+        _lib.check(self._lib.wfl_set_average_languages(self._handle, arr, len(ids)), "wfl_set_average_languages")
 
     def eval(self):
         return self
@@ -108,17 +137,21 @@ class BIOPhonemeTagger:
     def num_frames(self, L: int) -> int:
         return int(self._lib.wfl_num_frames(self._handle, int(L)))
 
-    def _workspace(self, B: int, L: int, device, slot: int = 0):
-        need = int(self._lib.wfl_workspace_bytes(self._handle, B, L))
+    def _workspace(self, B: int, L: int, device, slot: int = 0, need: int = 0):
+        need = need or int(self._lib.wfl_workspace_bytes(self._handle, B, L))
         if need <= 0:
             raise _lib.WflError("wfl_workspace_bytes failed")
+        if device != self.device:
+            raise _lib.WflError(f"input is on {device} but the model lives on {self.device}")
         if slot:                                    # extra workspaces: one per batch in flight on its own stream
             ws = self._ws_extra.get(slot)
             if ws is None or ws.numel() < need or ws.device != device:
+                if any(k[-1] == slot for k in self._graphs):
+                    raise _lib.WflError("workspace must not grow while captured graphs hold its address")
                 self._ws_extra[slot] = ws = torch.empty(need, dtype=torch.uint8, device=device)
             return ws
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            if self._graphs:
+            if any(k[-1] == 0 for k in self._graphs):
                 raise _lib.WflError("workspace must not grow while captured graphs hold its address; "
                                     "label the largest batch first or create a new tagger")
             self._ws = None
@@ -145,21 +178,22 @@ class BIOPhonemeTagger:
             rc = self._lib.wfl_forward(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(lang_t), mode,
                                        float(threshold), _ptr(ws), ws.numel(), _ptr(out.ids), _ptr(out.argmax),
                                        _ptr(out.maxprob), _ptr(out.offsets), _ptr(out.logits), _ptr(out.hidden),
-                                       C.c_void_p(stream))
+                                       _ptr(out.status), C.c_void_p(stream))
         _lib.check(rc, "wfl_forward")
 
     def _alloc_out(self, B, T, dev, want_logits, want_hidden) -> "TagBatch":
-        """ids | maxprob | offsets | argmax live in ONE allocation so the host side needs a single D2H copy
-        (`TagBatch.packed` = the first 4*B*T words: ids, max-prob bits, offsets bits)."""
+        """ids | maxprob | offsets | status | argmax live in ONE allocation so the host side needs a single D2H copy
+        (`TagBatch.packed` = the first 4*B*T + 1 words: ids, max-prob bits, offsets bits, the forward's status word)."""
         Cn = len(self.label_list)
         n = B * T
-        blob = torch.empty(5 * n, dtype=torch.int32, device=dev)
+        blob = torch.empty(5 * n + 1, dtype=torch.int32, device=dev)
         out = TagBatch(
-            blob[0:n].view(B, T), blob[4 * n:5 * n].view(B, T), blob[n:2 * n].view(torch.float32).view(B, T),
+            blob[0:n].view(B, T), blob[4 * n + 1:5 * n + 1].view(B, T), blob[n:2 * n].view(torch.float32).view(B, T),
             blob[2 * n:4 * n].view(torch.float32).view(B, T, 2),
             torch.empty(B, T, Cn, dtype=torch.float32, device=dev) if want_logits else None,
             torch.empty(B, T, self.hidden_size, dtype=torch.float32, device=dev) if want_hidden else None)
-        out.packed = blob[0:4 * n]
+        out.status = blob[4 * n:4 * n + 1]
+        out.packed = blob[0:4 * n + 1]
         return out
 
     @torch.no_grad()
@@ -168,10 +202,10 @@ class BIOPhonemeTagger:
               graph: bool = False, slot: int = 0) -> TagBatch:
         """The batched fast path: [B, L] fp32 16 kHz clips -> per-frame decisions (all on the GPU).
 
-        graph=True (experimental, off by default everywhere) replays the whole forward (about 100 kernel launches)
-        as one captured HIP graph per (B, L, mode) signature; inputs are copied into static buffers and the returned
-        tensors are the graph's static outputs (consume them before the next call with the same signature).  The
-        kernels are long enough that eager launches already keep the GPU busy (graph gain measured < 1 %).
+        graph=True (off by default) replays the whole forward (about 100 kernel launches) as one captured HIP graph per
+        (B, L, mode, slot) signature; inputs are copied into static buffers and the returned tensors are the graph's static
+        outputs (consume them before the next call with the same signature and slot).  The kernels are long enough that
+        eager launches already keep the GPU busy (graph gain measured < 1 %).
 
         slot: workspace index.  Batches labelled concurrently on different streams must use different slots (each slot owns
         a workspace); the forward itself keeps no other per-call state."""
@@ -204,7 +238,9 @@ class BIOPhonemeTagger:
             out = self._alloc_out(B, T, dev, want_logits, want_hidden)
             self._launch(x, lens_d, lang_d, mode, threshold, out, slot)
             return out
-        key = (B, L, mode, float(threshold), want_logits, want_hidden, lens_t is not None, dev.index)
+        # one graph per signature AND workspace slot: a graph owns static inputs/outputs and replays on its slot's workspace,
+        # so graphs of different slots may run concurrently on different streams (the slot is the key's last entry)
+        key = (B, L, mode, float(threshold), want_logits, want_hidden, lens_t is not None, dev.index, slot)
         g = self._graphs.get(key)
         if g is None:
             st = dict(
@@ -220,11 +256,11 @@ class BIOPhonemeTagger:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):           # warm-up outside capture (function attributes, workspace)
-                self._launch(st["x"], st["lens"], st["lang"], mode, threshold, st["out"])
+                self._launch(st["x"], st["lens"], st["lang"], mode, threshold, st["out"], slot)
             torch.cuda.current_stream(dev).wait_stream(side)
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
-                self._launch(st["x"], st["lens"], st["lang"], mode, threshold, st["out"])
+                self._launch(st["x"], st["lens"], st["lang"], mode, threshold, st["out"], slot)
             st["graph"] = cg
             self._graphs[key] = g = st
         g["x"].copy_(x, non_blocking=True)
@@ -237,20 +273,79 @@ class BIOPhonemeTagger:
         g["graph"].replay()
         return g["out"]
 
-    def check(self, B: int, L: int, device=None):
-        """Synchronise and raise if the last forward recorded a device-side error (BiLSTM hand-off time-out)."""
-        dev = torch.device(device) if device is not None else self._ws.device
-        ws = self._workspace(B, L, dev)
+    def check(self, B: int, L: int, device=None, slot: int = 0):
+        """Synchronise and raise if the last forward on workspace `slot` recorded a device-side error (BiLSTM hand-off
+        time-out).  The batched loops read the same word from `TagBatch.status` instead (no extra synchronisation)."""
+        dev = torch.device(device) if device is not None else self.device
+        ws = self._workspace(B, L, dev, slot)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(self._lib.wfl_check(self._handle, _ptr(ws), ws.numel(), B, L, C.c_void_p(stream)), "wfl_check")
 
     def forward(self, input_values, lang_id=None, max_label_len=None):
-        """Reference contract (model.py:148-194): returns (logits [B,T,C] f32, offsets [B,T,2] f32)."""
-        if max_label_len is not None:
-            raise NotImplementedError("max_label_len (training-time pad/truncate, model.py:166-174) is out of scope")
-        out = self.label(input_values, lang_id, want_logits=True)
+        """Reference contract (model.py:148-194): returns (logits [B,T,C] f32, offsets [B,T,2] f32).  With `max_label_len`
+        (the training-time validation forward, train.py:456-545) the encoder output is truncated / zero-padded to that many
+        frames before the head (model.py:166-174): wfl_encode -> pad/truncate -> wfl_head."""
+        if max_label_len is None:
+            out = self.label(input_values, lang_id, want_logits=True)
+            return out.logits, out.offsets
+        hidden = self.encode(input_values)
+        cur = hidden.size(1)
+        if cur > max_label_len:
+            hidden = hidden[:, :max_label_len, :].contiguous()
+        elif cur < max_label_len:
+            hidden = torch.cat([hidden, hidden.new_zeros(hidden.size(0), max_label_len - cur, hidden.size(2))], dim=1)
+        out = self.head(hidden, lang_id, want_logits=True)
         return out.logits, out.offsets
+
+    @torch.no_grad()
+    def encode(self, input_values: torch.Tensor, lens=None) -> torch.Tensor:
+        """[B, L] fp32 16 kHz -> encoder output [B, T, d] fp32 (model.py:149-161; wfl_encode)."""
+        if not self._ready:
+            raise _lib.WflError("load_state_dict() has not been called")
+        x = input_values.to(torch.float32)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        B, L = x.shape
+        hidden = torch.empty(B, self.num_frames(L), self.hidden_size, dtype=torch.float32, device=x.device)
+        lens_d = torch.as_tensor(lens).to(torch.int32).reshape(-1).to(x.device) if lens is not None else None
+        ws = self._workspace(B, L, x.device)
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = self._lib.wfl_encode(self._handle, _ptr(x), x.stride(0), _ptr(lens_d), B, L, _ptr(ws), ws.numel(), _ptr(hidden),
+                                      C.c_void_p(stream))
+        _lib.check(rc, "wfl_encode")
+        return hidden
+
+    @torch.no_grad()
+    def head(self, hidden: torch.Tensor, lang_id=None, threshold: float = 0.0, average_languages: bool = False,
+             want_logits: bool = False) -> TagBatch:
+        """Encoder output [B, T, d] fp32 (any T) -> decisions (model.py:176-194 + infer.py:86-96; wfl_head)."""
+        if not self._ready:
+            raise _lib.WflError("load_state_dict() has not been called")
+        if hidden.dim() != 3 or hidden.size(2) != self.hidden_size or not hidden.is_cuda:
+            raise ValueError("hidden must be a CUDA tensor [B, T, d_model]")
+        h = hidden.to(torch.float32).contiguous()
+        B, T, _ = h.shape
+        dev = h.device
+        lang_t = None
+        if average_languages:
+            mode = LANG_AVERAGE
+        elif lang_id is None:
+            mode = LANG_NONE
+        else:
+            mode = LANG_IDS
+            lang_t = self._check_lang(lang_id, B).to(dev).contiguous()
+        need = int(self._lib.wfl_head_workspace_bytes(self._handle, B, T))
+        ws = self._workspace(B, 0, dev, slot=-1, need=need)       # its own slot: a head-only plan lays the workspace out differently
+        out = self._alloc_out(B, T, dev, want_logits, False)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = self._lib.wfl_head(self._handle, _ptr(h), B, T, _ptr(lang_t), mode, float(threshold), _ptr(ws), ws.numel(),
+                                    _ptr(out.ids), _ptr(out.argmax), _ptr(out.maxprob), _ptr(out.offsets), _ptr(out.logits),
+                                    _ptr(out.status), C.c_void_p(stream))
+        _lib.check(rc, "wfl_head")
+        return out
 
     __call__ = forward
 
