@@ -77,6 +77,22 @@ struct AttnArgs {
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
 };
 
+// One BiLSTM layer's recurrence (lstm.hip)
+struct LstmArgs {
+  const float* gx; long ldgx;      // frame rows, fp32: col = dir*4H + 4*unit + gate
+  const bf16_t* whh;               // [2][G][4U][H] bf16, slice rows = 4*u_local + gate
+  bf16_t* out; long ldo;           // frame rows: col = dir*H + unit
+  long lead;
+  int B, T, P, H, U, G;
+  unsigned long long* hx;          // exchange granules: [2 dir][groups][2 parity][H/8 blocks of 8 units][16 clips][4]
+  unsigned* error;                 // the forward's error word (ORed into)
+  int grp0;                        // first clip group of this launch
+  int ngroups;                     // clip groups of the whole batch (exchange indexing)
+#ifdef WFL_LSTM_STAMPS
+  unsigned long long* stamps;      // diagnostic build (tools/micro/lstm_bench.hip): [steps 64..95][8] phase stamps of WG (0,0,0) wave 0
+#endif
+};
+
 // erf GELU (nn.GELU() default / HF "gelu"):  gelu(x) = max(x, 0) - |x| * Phi(-|x|),  Phi(-t) = 0.5 * erfc(t / sqrt 2).
 // log2 Phi(-t) is smooth and nearly quadratic, so Phi(-t) = exp2(q(t)) with q a degree-5 minimax fit on [0, 6] weighted
 // by the error it causes in gelu (tools/fit_gelu.py): |gelu error| <= 6.4e-7 over all x in fp32 (the bf16 rounding of the

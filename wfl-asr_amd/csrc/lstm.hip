@@ -3,229 +3,316 @@
 // zero initial state, both biases, outputs concat(fwd, bwd); padded frames do not exist here (every clip in a
 // batch has the same T).
 //
-// The input projection x W_ih^T + b_ih + b_hh of BOTH directions is one big MFMA GEMM (gemm.hip) into fp32 `gx`,
+// The input projection x W_ih^T + b_ih + b_hh of BOTH directions is one big MFMA GEMM (gemm256.hip) into fp32 `gx`,
 // with the gate rows reordered unit-major / gate-minor so that one float4 holds (i,f,g,o) of one hidden unit.
 // This kernel only runs the recurrence  gates_t = gx_t + W_hh h_{t-1}  as a persistent launch:
 //
-//   grid = (G slices of the hidden units) x (groups of 16 clips) x (2 directions), 256 threads, one WG per CU.
-//   WG (slice, group, dir) keeps its 4U x H slice of W_hh in LDS for all T steps (rows ordered unit-major /
-//   gate-minor: an MFMA 16x16x32 tile = 4 units x 4 gates, so every lane ends up with the four gates of ONE unit
-//   of ONE clip and the cell update is lane-local; the cell state lives in registers for all T steps).
-//   Per step the G slice WGs of a (group, dir) exchange their U new hidden values through a ping-pong buffer in
-//   global memory with the write-through hand-off of cdna_hip_programming.md Guideline 16 (R1, counter form):
-//   wave 0 stores the slice as whole 1 KiB chunks with sc1 stores, drains them (vmcnt(0)), then ONE lane adds 1 to a
-//   monotonic agent-scope counter; consumers poll that counter with sc1 loads (one lane, s_sleep, bounded),
-//   pass a workgroup barrier and read h_{t-1} with sc1 16-byte loads straight into MFMA B-operand fragments.
-//   Ping-pong is WAR-safe: nobody can publish step s+2 before every WG consumed step s (it needs all of s+1).
-//   A spin that gives up sets a sticky error word (checked by the host) instead of hanging the GPU.
+//   grid = (G slices of the hidden units) x (groups of 16 clips) x (2 directions), 256 threads = 4 waves, one WG per CU.
+//   * W_hh lives in REGISTERS for all T steps: WG (slice, group, dir) owns the 4U x H slice of U = 32 units, each wave
+//     the MFMA A-operand fragments of its two 16-row tiles (4 units x 4 gates each): 2 x H/32 bf16x8 per lane
+//     (64 VGPRs at H = 256, 160 at H = 640).  Round 1 kept a 64-unit slice in LDS and re-read 128 KiB of it per step
+//     (0.22 us of LDS time on the critical path, and 133 KiB of LDS per WG).
+//   * A wave's tiles come in pairs holding the even / odd units of 8 consecutive units, so lane (g, c) ends up with
+//     the four gates of units 8p + 2g and 8p + 2g + 1 of clip c: the cell update is lane-local (cell state in
+//     registers for all T steps) and the two new hidden values are one 4-byte run of the output row.
+//   * Per step the G slice WGs of a (group, dir) exchange h through global memory as self-validating 8-byte GRANULES
+//     {2 x bf16 h, 32-bit tag = step + 1} (MI355X_MICROARCH.md, hand-off price list: granule = one naturally aligned 8-byte
+//     {data, tag} written by ONE sc1 store; observed untorn): the producer's lanes store their granule straight from
+//     registers (write-through, no LDS staging, no drain, no counter), consumers poll the granules themselves with sc1
+//     16-byte loads (two granules each) until every tag shows the step they wait for, strip the tags into a
+//     fragment-ordered LDS image (one ds_write_b128 per K step and lane), pass ONE workgroup barrier and read their MFMA B
+//     fragments back.  Round 1's hand-off (1 KiB sc1 stores, vmcnt(0) drain, agent-scope counter add, one polling lane,
+//     barrier, sc1 fragment loads by every wave) cost ~5.8 us per step; this one 1.76 us (H = 256).  A wave's granule stores
+//     cover whole 128-byte lines (image layout [block of 8 units][clip][4 granules]: one store instruction = 512 contiguous
+//     bytes); with 32-byte pieces of four different lines per instruction the same step took 2.44 us.
+//     Ping-pong (two granule images, two LDS images) is WAR-safe: nobody can publish step s+2 before every WG consumed
+//     step s (it needs all of s+1).  Tags of an earlier launch are cleared by a fill kernel in front of every launch.
+//   * gx of the next four steps is prefetched into a register ring (HBM latency > one step).
+//   A poll that gives up ORs bit 0 into the forward's error word (wfl_asr.h: status) instead of hanging the GPU, and the
+//   launch finishes without further waiting.  Launches are cut so that one launch never needs more than 128 resident
+//   workgroups: two such launches (two batches in flight on two streams) always fit the 256 CUs together.
 #include "common.h"
 #include <cstdlib>
-
-struct LstmArgs {
-  const float* gx; long ldgx;      // frame rows, fp32: col = dir*4H + 4*unit + gate
-  const bf16_t* whh;               // [2][G][4U][H] bf16, slice rows = 4*u_local + gate
-  bf16_t* out; long ldo;           // frame rows: col = dir*H + unit
-  long lead;
-  int B, T, P, H, U, G;
-  bf16_t* hx;                      // exchange: [2 dir][groups][2 parity][G][16][U]
-  unsigned* counters;              // [2 dir][groups], zeroed by the launcher
-  unsigned* error;                 // sticky time-out word
-};
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 static __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 static __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-template <int H>
-static __device__ __forceinline__ int w_swz(int row) {
-  constexpr int CPR = H / 8;
-  if (CPR >= 16) return row & 15;
-  if (CPR == 8) return (row >> 1) & 7;
-  return (row >> 2) & 3;
-}
+#ifdef WFL_LSTM_STAMPS
+#define LSTAMP(k) do { if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && s >= 64 && s < 96) \
+    p.stamps[(s - 64) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LSTAMP(k) do { } while (0)
+#endif
+#define LSTM_SC1 16            // buffer cache policy: sc1 (agent scope: served / written at the memory side of L2)
+#define LSTM_SPIN_LIMIT 3000000u
+#ifndef LSTM_STAGGER
+#define LSTM_STAGGER 4           // s_sleep units (64 clocks) between two poll attempts
+#endif
 
-template <int H, int MAXT>   // MAXT = MFMA tiles (4 units each) per wave
+template <int H, int MAXT>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
 __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KS = H / 32;
-  constexpr int CPR = H / 8;
+  static_assert(MAXT % 2 == 0, "tiles are paired");
+  constexpr int KS = H / 32;                     // K steps of 32 hidden units
+  constexpr int D = 4;                           // gx prefetch distance (steps)
+  constexpr int NP = MAXT / 2;                   // tile pairs per wave
+  __shared__ bf16x8 hfrag[2][KS][64];            // h_{t-1} as MFMA B fragments: [parity][K step][lane]
+  __shared__ int dflag;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int slice = blockIdx.x, grp = blockIdx.y, dir = blockIdx.z;
+  const int slice = blockIdx.x, grp = p.grp0 + blockIdx.y, dir = blockIdx.z;
   const int U = p.U, G = p.G;
-  const int ntile = U / 4;                       // tiles of this WG
-  char* Ws = smem;                               // [4U][H] bf16, swizzled 16-byte chunks
-  bf16_t* hst = (bf16_t*)(smem + 4 * U * H * 2);  // [16][U] staging of the new hidden values
-  int* dflag = (int*)(smem + 4 * U * H * 2 + 16 * U * 2);   // a spin gave up (block-wide)
-  if (tid == 0) *dflag = 0;
+  const int npair = U >> 3;
+  if (tid == 0) dflag = 0;
 
-  // ---- W_hh slice -> LDS (once)
-  {
-    const bf16_t* wsrc = p.whh + ((long)(dir * G + slice) * 4 * U) * H;
-    const int nchunk = 4 * U * CPR;
-    for (int i = tid; i < nchunk; i += 256) {
-      const int r = i / CPR, cc = i % CPR;
-      *(bf16x8*)(Ws + r * (H * 2) + ((cc ^ w_swz<H>(r)) << 4)) = *(const bf16x8*)(wsrc + (long)r * H + cc * 8);
+  // ---- W_hh fragments -> registers (once).  MFMA A row a = lane & 15 of tile (pair pp, parity e) is gate a & 3 of unit
+  // 8 pp + 2 (a >> 2) + e; the lane supplies k = 32 ks + 8 g .. + 8.
+  bf16x8 w[MAXT][KS];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    // (a wave whose pair index is beyond the slice -- only with the narrow slices of the test hook -- runs the same code on
+    // the last valid pair's data and stores nothing: no per-tile control flow inside the step)
+    const int pp = wid + 4 * (i >> 1) < npair ? wid + 4 * (i >> 1) : npair - 1, e = i & 1;
+    const int ul = 8 * pp + 2 * (c >> 2) + e;
+    const bf16_t* wsrc = p.whh + (((long)(dir * G + slice) * 4 * U) + 4 * ul + (c & 3)) * H + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      w[i][ks] = *(const bf16x8*)(wsrc + ks * 32);
+      // Opaque to the compiler from here on: an invariant global load is "rematerialisable", and hipcc then re-loads all
+      // 32 KiB of a wave's fragments from L2 in every step (measured: 2.1 us per step) instead of keeping them in registers.
+      asm volatile("" : "+v"(w[i][ks]));
     }
   }
-  __syncthreads();
 
   const int clip = grp * 16 + c;
   const int clip_rd = clip < p.B ? clip : p.B - 1;
-  const long ngroups = gridDim.y;
-  bf16_t* hx = p.hx + ((long)(dir * ngroups + grp) * 2) * G * 16 * U;       // [parity][G][16][U]
-  unsigned* counter = p.counters + dir * ngroups + grp;
-  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 2 * G * 16 * U * 2, 0x00020000);
+  const long gran_per_img = 16L * (H / 2);                                    // granules per parity image
+  unsigned long long* hx = p.hx + ((long)(dir * p.ngroups + grp) * 2) * gran_per_img;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)(2 * gran_per_img * 8), 0x00020000);
 
   float cstate[MAXT];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) cstate[i] = 0.f;
-  bool dead = false;                             // a spin gave up: stop waiting, finish the launch
+  bool dead = false;                             // a poll gave up: stop waiting, finish the launch
 
-  // gx of step 0
-  f32x4 gxv[MAXT];
-  auto load_gx = [&](int t) {
-    const float* gp = p.gx + (p.lead + (long)clip_rd * p.P + t) * p.ldgx + dir * 4 * H;
+  // gx register ring: gxv[r][i] = pre-activations (i,f,g,o) of this lane's unit of tile i at step s, s % D == r
+  f32x4 gxv[D][MAXT];
+  const float* gx_lane = p.gx + (p.lead + (long)clip_rd * p.P) * p.ldgx + dir * 4 * H + 4 * (slice * U + 2 * g);
+  auto load_gx = [&](int s, auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    const int t = dir == 0 ? s : p.T - 1 - s;
+    const float* gp = gx_lane + (long)t * p.ldgx;
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-      const int tile = wid + 4 * i;
-      if (tile < ntile) gxv[i] = *(const f32x4*)(gp + 4 * (slice * U + tile * 4 + g));
+      const int pp = wid + 4 * (i >> 1) < npair ? wid + 4 * (i >> 1) : npair - 1;
+      gxv[r][i] = *(const f32x4*)(gp + 4 * (8 * pp + (i & 1)));
     }
   };
-  load_gx(dir == 0 ? 0 : p.T - 1);
+  if (0 < p.T) load_gx(0, std::integral_constant<int, 0>{});
+  if (1 < p.T) load_gx(1, std::integral_constant<int, 1>{});
+  if (2 < p.T) load_gx(2, std::integral_constant<int, 2>{});
+  if (3 < p.T) load_gx(3, std::integral_constant<int, 3>{});
+  __syncthreads();
 
-  for (int s = 0; s < p.T; ++s) {
+  auto step = [&](int s, auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
     const int t = dir == 0 ? s : p.T - 1 - s;
     f32x4 acc[MAXT];
+    bf16x8 hf[KS];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) acc[i] = gxv[i];
-    if (s + 1 < p.T) load_gx(dir == 0 ? s + 1 : p.T - 2 - s);     // prefetch: independent of the recurrence
+    for (int i = 0; i < MAXT; ++i) acc[i] = gxv[r][i];
+    LSTAMP(0);
 
     if (s > 0) {
-      // ---- wait until all G slices of step s-1 are published
-      if (tid == 0 && !dead) {
-        const unsigned target = (unsigned)G * (unsigned)s;
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > 1000000u) { atomicOr(p.error, 1u); *dflag = 1; break; }
-        }
-      }
-      __syncthreads();
-      if (*dflag) dead = true;
-      // ---- gates += W_slice . h_{s-1}   (h read with sc1 loads straight into B fragments)
+      // ---- gather h_{s-1}: this wave's K steps (ks = wid, wid + 4, ...), two 16-byte loads = four granules per K step
       const int par = (s - 1) & 1;
+      const unsigned want = (unsigned)s;            // tag of step s-1
+      constexpr int NK = (KS + 3) / 4;
+      if (!dead) {
+        // Two poll attempts in flight, issued half a round trip apart (a failed attempt costs a whole ~0.6 us round trip; the
+        // loads return in issue order, so attempt n + 1 is already on its way when attempt n is examined).
+        u32x4 ga0[NK], gb0[NK], ga1[NK], gb1[NK];
+        auto issue = [&](u32x4* ga, u32x4* gb) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int k = ks * 32 + 8 * g;
-        const int sl = k / U, within = k - sl * U;
-        const unsigned off = (unsigned)((((par * G + sl) * 16 + c) * U + within) * 2);
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, 16);
-        bf16x8 hf;
-        __builtin_memcpy(&hf, &raw, 16);
+          for (int j = 0; j < NK; ++j) {
+            const int ks = wid + 4 * j;
+            if (ks < KS) {
+              const unsigned off = (unsigned)((((par * (H / 8) + 4 * ks + g) * 16) + c) * 32);
+              ga[j] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, LSTM_SC1);
+              gb[j] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off + 16, 0, LSTM_SC1);
+            }
+          }
+        };
+        auto landed = [&](const u32x4* ga, const u32x4* gb) __attribute__((always_inline)) {
+          bool ok = true;
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i) {
-          const int tile = wid + 4 * i;
-          if (tile < ntile) {
-            const int r = tile * 16 + c;
-            const bf16x8 wf = *(const bf16x8*)(Ws + r * (H * 2) + (((ks * 4 + g) ^ w_swz<H>(r)) << 4));
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf, acc[i], 0, 0, 0);
+          for (int j = 0; j < NK; ++j) {
+            const int ks = wid + 4 * j;
+            if (ks < KS) ok = ok && ga[j][1] == want && ga[j][3] == want && gb[j][1] == want && gb[j][3] == want;
+          }
+#ifdef WFL_LSTM_NOWAIT
+          return true;
+#endif
+          return (bool)__all(ok);
+        };
+        auto stage_lds = [&](const u32x4* ga, const u32x4* gb) __attribute__((always_inline)) {   // strip the tags
+#pragma unroll
+          for (int j = 0; j < NK; ++j) {
+            const int ks = wid + 4 * j;
+            if (ks < KS) {
+              u32x4 d = {ga[j][0], ga[j][2], gb[j][0], gb[j][2]};
+              bf16x8 hv;
+              __builtin_memcpy(&hv, &d, 16);
+              hfrag[par][ks][lane] = hv;
+            }
+          }
+        };
+        unsigned spins = 0;
+#ifdef WFL_LSTM_POLL2
+        issue(ga0, gb0);
+        for (;;) {
+          __builtin_amdgcn_s_sleep(LSTM_STAGGER);
+          issue(ga1, gb1);
+          if (landed(ga0, gb0)) { LSTAMP(1); stage_lds(ga0, gb0); break; }
+          __builtin_amdgcn_s_sleep(LSTM_STAGGER);
+          issue(ga0, gb0);
+          if (landed(ga1, gb1)) { LSTAMP(1); stage_lds(ga1, gb1); break; }
+          if ((spins += 2) > LSTM_SPIN_LIMIT) {
+            if (lane == 0) { atomicOr(p.error, 1u); dflag = 1; }
+            break;
           }
         }
+#else
+        for (;;) {
+          issue(ga0, gb0);
+          if (landed(ga0, gb0)) { LSTAMP(1); stage_lds(ga0, gb0); break; }
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > LSTM_SPIN_LIMIT) {
+            if (lane == 0) { atomicOr(p.error, 1u); dflag = 1; }
+            break;
+          }
+        }
+#endif
       }
-    }
-
-    // ---- cell update: acc[i] = (i, f, g, o) pre-activations of unit slice*U + tile*4 + g, clip c
+      // refill the gx slot just consumed -- AFTER the poll: vmcnt retires in issue order, so a poll behind these HBM loads
+      // would wait for them as well
+      if (s + D < p.T) load_gx(s + D, rc);
+      __syncthreads();
+      LSTAMP(2);
+      if (dflag) dead = true;
+      // ---- gates += W_slice . h_{s-1}: all K-step fragments first, then one tile pair at a time, so that the cell update of a
+      // pair (vector pipe) can run beside the next pair's MFMAs (matrix pipe)
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int tile = wid + 4 * i;
-      if (tile < ntile) {
+      for (int ks = 0; ks < KS; ++ks) hf[ks] = hfrag[par][ks][lane];
+    } else {
+      if (D < p.T) load_gx(D, rc);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) hf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // h_{-1} = 0
+    }
+#ifdef WFL_LSTM_KMAJOR
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][ks], hf[ks], acc[i], 0, 0, 0);
+#endif
+    LSTAMP(3);
+    // ---- cell update: acc[i] = (i, f, g, o) pre-activations of unit 8 pp + 2 g + (i & 1), clip c
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+      const int pp = wid + 4 * ip;
+#ifndef WFL_LSTM_KMAJOR
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          acc[2 * ip + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * ip + e][ks], hf[ks], acc[2 * ip + e], 0, 0, 0);
+#endif
+      bf16_t hb[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = 2 * ip + e;
         const float ig = sigm(acc[i][0]), fg = sigm(acc[i][1]), gg = tanh_(acc[i][2]), og = sigm(acc[i][3]);
         cstate[i] = fg * cstate[i] + ig * gg;
-        const float h = og * tanh_(cstate[i]);
-        const bf16_t hb = f2bf(h);
-        const int ul = tile * 4 + g;
-        hst[c * U + ul] = hb;
+        hb[e] = f2bf(og * tanh_(cstate[i]));
+      }
+      unsigned bits;
+      __builtin_memcpy(&bits, hb, 4);
+      const int u0 = slice * U + 8 * pp + 2 * g;                   // first of this lane's two consecutive units
+      if (pp < npair) {
+        if (s + 1 < p.T) {                                         // publish: one granule, write-through
+          const unsigned off = (unsigned)((((((s & 1) * (H / 8) + (u0 >> 3)) * 16) + c) * 4 + g) * 8);
+          const u32x2 gr = {bits, (unsigned)(s + 1)};
+          __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, LSTM_SC1);
+        }
+        if (clip < p.B) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
       }
     }
-    __syncthreads();
-    // ---- publish: wave 0 writes the [16][U] slice as whole 1 KiB chunks, write-through, then signals once
-    if (wid == 0 && s + 1 < p.T) {
-      const int par = s & 1;
-      const int nbytes = 16 * U * 2;
-      const unsigned base = (unsigned)(((par * G + slice) * 16) * U * 2);
-      for (int o = lane * 16; o < nbytes; o += 1024) {
-        u32x4 v;
-        __builtin_memcpy(&v, (const char*)hst + o, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, hx_rsrc, base + o, 0, 16);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // waves 1-3: the same tile to the layer's output frame rows, 16 bytes per lane
-    if (wid > 0) {
-      const int cpr = U / 8;                   // 16-byte chunks per clip
-      for (int ch = tid - 64; ch < 16 * cpr; ch += 192) {
-        const int cl = ch / cpr, part = ch - cl * cpr;
-        const int clipw = grp * 16 + cl;
-        if (clipw < p.B)
-          *(bf16x8*)(p.out + (p.lead + (long)clipw * p.P + t) * p.ldo + dir * H + slice * U + part * 8) =
-              *(const bf16x8*)(hst + cl * U + part * 8);
-      }
-    }
-    // the next step's barrier (after the poll) also protects hst against the next cell update
+    LSTAMP(4);
+  };
+
+  for (int s0 = 0; s0 < p.T; s0 += D) {
+    step(s0, std::integral_constant<int, 0>{});
+    if (s0 + 1 < p.T) step(s0 + 1, std::integral_constant<int, 1>{});
+    if (s0 + 2 < p.T) step(s0 + 2, std::integral_constant<int, 2>{});
+    if (s0 + 3 < p.T) step(s0 + 3, std::integral_constant<int, 3>{});
   }
 }
 
 template <int H, int MAXT>
 static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
-  const int lds = 4 * a.U * H * 2 + 16 * a.U * 2 + 16;
-  auto k = lstm_kernel<H, MAXT>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
-    attr_lds = lds;
-  }
-  hipLaunchKernelGGL(k, dim3(a.G, groups, 2), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((lstm_kernel<H, MAXT>), dim3(a.G, groups, 2), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// Units per WG: the largest multiple of 8 dividing H whose 4U x H bf16 slice fits ~128 KiB of LDS (<= 64 units)
+// Units per WG: 32 (four waves x one pair of 16-row tiles) when it divides H, else the largest multiple of 8 below that does.
+// Measured at H = 256, 16 clips (tools/micro/lstm_bench.hip): 64 units per WG (4 WGs per direction) 2.14 us per step, 32 units
+// (8 WGs) 1.76 us, 16 units 1.77 us -- the step is hand-off latency plus one WG's own MFMA + cell update, so halving the slice
+// pays until the gather's fan-in takes it back.
 int wfl_lstm_units_per_wg(int H) {
   if (const char* e = getenv("WFL_LSTM_UNITS")) {        // test hook: force a slice width (more WGs per direction)
     const int U = atoi(e);
-    if (U >= 8 && U % 8 == 0 && U <= H && H % U == 0 && 4L * U * H * 2 + 16 * U * 2 <= 132 * 1024) return U;
+    if (U >= 8 && U % 8 == 0 && U <= 32 && U <= H && H % U == 0) return U;
   }
   int best = 0;
-  for (int U = 8; U <= 64 && U <= H; U += 8)
-    if (H % U == 0 && 4L * U * H * 2 + 16 * U * 2 <= 132 * 1024) best = U;
+  for (int U = 8; U <= 32 && U <= H; U += 8)
+    if (H % U == 0) best = U;
   return best;
 }
 
 long wfl_lstm_exchange_bytes(int H, int B) {
   const long groups = (B + 15) / 16;
-  return 2 * groups * 2 * 16 * (long)H * 2 + 2 * groups * 4 + 64;     // hx + counters + error word
+  return 2 * groups * 2 * 16 * (long)(H / 2) * 8 + 64;     // granule images: [2 dir][groups][2 parity][H/8][16][4] x 8 bytes
 }
 
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
-  if (a.U <= 0 || a.U % 8 || a.H % a.U || a.H % 32 || a.ldgx % 4 || a.ldo % 8 || a.T <= 0 || a.B <= 0) return -1;
+  if (a.U <= 0 || a.U % 8 || a.U > 32 || a.H % a.U || a.H % 32 || a.ldgx % 4 || a.ldo % 8 || a.T <= 0 || a.B <= 0) return -1;
+  if (!a.error) return -1;                 // the forward's error word (ORed into, never cleared here)
   a.G = a.H / a.U;
   const int groups = (a.B + 15) / 16;
-  if ((long)a.G * groups * 2 > 256) return -5;         // every WG must be resident (one per CU): split the batch
-  const long hx_bytes = 2L * groups * 2 * 16 * a.H * 2;
-  a.hx = (bf16_t*)exchange;
-  a.counters = (unsigned*)((char*)exchange + hx_bytes);
-  if (!a.error) return -1;                 // the forward's error word (ORed into, never cleared here)
-  if (wfl_launch_fill_i32((int*)a.counters, 2 * groups, 0, s)) return -3;   // (a kernel, not a memset node: common.h)
-  const int maxt = (a.U / 4 + 3) / 4;
-  switch (a.H) {
-    case 32: return maxt <= 2 ? launch_lstm_t<32, 2>(a, groups, s) : -4;
-    case 256: return launch_lstm_t<256, 4>(a, groups, s);
-    case 384: return launch_lstm_t<384, 4>(a, groups, s);
-    case 512: return launch_lstm_t<512, 4>(a, groups, s);
-    case 640: return launch_lstm_t<640, 4>(a, groups, s);
+  if (2 * a.G > 128) return -5;
+  a.hx = (unsigned long long*)exchange;
+  a.ngroups = groups;
+  // tags of an earlier launch must not validate: clear the granule images (a kernel, not a memset node: common.h)
+  if (wfl_launch_fill_i32((int*)exchange, 2L * groups * 2 * 16 * (a.H / 2) * 2, 0, s)) return -3;
+  // at most 128 resident workgroups per launch, so that two launches in flight (two streams) always fit the chip together
+  const int per = 128 / (2 * a.G) > 0 ? 128 / (2 * a.G) : 1;
+  for (int g0 = 0; g0 < groups; g0 += per) {
+    a.grp0 = g0;
+    const int n = groups - g0 < per ? groups - g0 : per;
+    int r;
+    switch (a.H) {
+      case 32: r = launch_lstm_t<32, 2>(a, n, s); break;
+      case 256: r = launch_lstm_t<256, 2>(a, n, s); break;
+      case 384: r = launch_lstm_t<384, 2>(a, n, s); break;
+      case 512: r = launch_lstm_t<512, 2>(a, n, s); break;
+      case 640: r = launch_lstm_t<640, 2>(a, n, s); break;
+      default: return -4;
+    }
+    if (r) return r;
   }
-  return -4;
+  return 0;
 }

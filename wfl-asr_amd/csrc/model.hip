@@ -45,16 +45,6 @@ struct TagArgs {
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
 int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s);
 
-struct LstmArgs {
-  const float* gx; long ldgx;
-  const bf16_t* whh;
-  bf16_t* out; long ldo;
-  long lead;
-  int B, T, P, H, U, G;
-  bf16_t* hx;
-  unsigned* counters;
-  unsigned* error;
-};
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s);
 
 struct Conv0Args {
@@ -1199,7 +1189,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
         la.error = (unsigned*)(R.ws + p.err);
         R.stats_for = nullptr;
         const int lr = wfl_launch_lstm(la, R.ws + p.lstm_x, R.s);
-        if (lr) return fail(lr, lr == -5 ? "BiLSTM: batch too large for one resident launch (max 256 / (2 * H/U) groups of 16 clips)"
+        if (lr) return fail(lr, lr == -5 ? "BiLSTM: hidden size too large (more than 64 slice workgroups per direction)"
                                           : "lstm launch failed (" + std::to_string(lr) + ")");
         std::swap(H, S);
       }
