@@ -2,21 +2,28 @@
 """Headline benchmark: audio-seconds labeled per second per node (BASELINE.json metric).
 
 One process per GPU (`--gpus N`; for N > 1 launched by torch.distributed.run, RCCL backend).  A step is one pass of
-the labeling hot path over one batch of synthetic 30 s clips that is already resident in HBM:
-  log-mel -> Whisper-base encoder -> lang_proj -> 2 Conformer blocks -> classifier + offset head -> tag decision
-  -> (N > 1: RCCL gather of the tag tensors to rank 0) -> tags copied to pinned host memory on the owning rank.
-Workload = BASELINE.json configs[1]: Whisper-base + 2 Conformer blocks, bf16, 16 x 30 s clips per GPU (weak scaling:
-the clips are independent, ranks share nothing but the final gather).  Steps alternate between `--inflight` (default 2)
-HIP streams, each with its own workspace and pinned host buffer, so two batches are in flight per GPU and one batch's
-kernel tails and HBM-bound epilogues overlap the other's kernels (+8-9 % measured; every step is still a complete pass
-over its own batch, and all K steps are inside the timed, fenced region).
+the labeling hot path over one batch of synthetic clips that is already resident in HBM:
+  log-mel / conv feature encoder -> Whisper or WavLM encoder -> lang_proj -> BiLSTM / Conformer / dilated-conv head ->
+  classifier + offset head -> tag decision -> (N > 1: ONE RCCL gather of the packed tags to rank 0) -> tags copied to pinned
+  host memory on the owning rank.
+Default workload = BASELINE.json configs[1]: Whisper-base + 2 Conformer blocks, bf16, 16 x 30 s clips per GPU (weak scaling:
+the clips are independent, ranks share nothing but the final gather).  `--config-index 2|3|4` selects the other BASELINE
+configs at their per-GPU sizes (64 x 10 s WavLM-large + BiLSTM + dilated; 64 x 30 s Whisper-small + full head; 32 x 30 s
+Whisper-large-v3), `--full-head` the reference's default config.yaml head on Whisper-base.  Steps alternate between `--inflight`
+(default 2) HIP streams, each with its own workspace and pinned host buffer, so two batches are in flight per GPU (every step
+is still a complete pass over its own batch, and all K steps are inside the timed, fenced region).
 
 Besides the contract fields the JSON line carries
-  roofline      the dominant kernel (bf16 MFMA GEMM family): algorithmic FLOPs / HIP-event time per launch, measured on
-                the launch stream in a second pass over the same K steps (one batch at a time, so nothing else shares the
-                GPU with the kernel being timed), against the 2.5 PFLOP/s dense bf16 MFMA peak
-  cpu_baseline  the oracle (pure-torch fp32 CPU restatement of the reference forward, kind "port") timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  roofline        the dominant kernel family (bf16 MFMA GEMMs): algorithmic FLOPs / HIP-event time per launch, measured on the
+                  launch stream in a second pass over the same K steps (one batch at a time, so nothing else shares the GPU with
+                  the kernel being timed), against the 2.5 PFLOP/s dense bf16 MFMA peak; `breakdown_ms_per_step` gives the same
+                  event timing for attention, the BiLSTM recurrence, log-mel and LayerNorm
+  value_with_h2d  the same K steps with the waveforms crossing PCIe inside the step: >= 8 distinct pinned host batches in
+                  rotation, copied on a separate stream that runs ahead of the compute streams (SURVEY.md §8d metric definition:
+                  "from first H2D of a batch"); `value` itself keeps the inputs resident, as the bench contract asks
+  cpu_baseline    the oracle (pure-torch fp32 CPU restatement of the reference forward, kind "port") timed on this box's host
+                  cores on a bounded sample of the same workload, at B = 1 per call (the reference's own loop, infer.py:261)
+                  and batched (rank 0, N = 1 only)
 """
 import argparse
 import json
@@ -30,9 +37,12 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-CLIP_SECONDS = 30.0
 SR = 16000
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+# per-GPU batch and clip length of the BASELINE configs (cfg3 64 x 10 s, cfg4 512 / 8, cfg5 256 / 8)
+CONFIG_SHAPE = {1: (16, 30.0), 2: (64, 10.0), 3: (64, 30.0), 4: (32, 30.0)}
+OTHER_KEYS = {2040: "attention (attn_kernel*)", 2041: "BiLSTM recurrence (lstm_kernel)", 2042: "log-mel (logmel_*_kernel)",
+              2043: "LayerNorm (layernorm_kernel)"}
 
 
 def parse():
@@ -40,18 +50,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="30 s clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: the BASELINE config's per-GPU batch)")
+    ap.add_argument("--clip-seconds", type=float, default=0.0, help="default: the BASELINE config's clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2, help="clips per CPU-baseline call")
-    ap.add_argument("--cpu-calls", type=int, default=3)
-    ap.add_argument("--no-kernel-events", action="store_true", help="skip the HIP-event pass that times every GEMM launch")
+    ap.add_argument("--cpu-clips", type=int, default=0, help="clips per batched CPU-baseline call (default 16 for configs[1], else 4)")
+    ap.add_argument("--cpu-calls", type=int, default=5)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the HIP-event pass that times every launch")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the with-H2D leg")
     ap.add_argument("--graph", action="store_true",
-                    help="replay one captured HIP graph per step instead of launching eagerly (experimental: measured gain "
-                         "< 1 %, and a replay was seen to diverge from eager when several graphs share the workspace)")
+                    help="replay one captured HIP graph per step and workspace slot instead of launching eagerly (measured gain < 1 %%)")
     ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight per GPU: step i runs on stream i %% inflight with its own workspace and host buffer, so "
-                         "one batch's kernel tails / HBM-bound epilogues overlap the next batch's kernels")
-    ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (Whisper configs only)")
+                    help="batches in flight per GPU: step i runs on stream i %% inflight with its own workspace and host buffer")
+    ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (1..4)")
     ap.add_argument("--full-head", action="store_true",
                     help="Whisper-base + the reference's default config.yaml head (2-layer BiLSTM, 2 Conformer, 2 dilated convs)")
     return ap.parse_args()
@@ -89,7 +99,18 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, labels, sd_np, clips, calls):
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, labels, sd_np, clips, calls, clip_seconds):
     """The oracle forward on host cores.  Only this leg (and tests / smoke) may touch oracle/."""
     from oracle import wfl_oracle as O
     from wfl_asr_amd import synth
@@ -99,24 +120,36 @@ def cpu_baseline(cfg, labels, sd_np, clips, calls):
     enc, arch = resolve_encoder_arch(cfg["model"])
     sd = O.to_torch_state_dict(sd_np)
     hc = synth.head_config(cfg["model"])
-    wav = torch.from_numpy(synth.make_batch(90000, clips, int(CLIP_SECONDS * SR), seed=1))
-    lang = torch.arange(clips) % cfg["model"]["num_languages"]
+    L = int(clip_seconds * SR)
+    wav_all = torch.from_numpy(synth.make_batch(90000, clips, L, seed=1))
     o_id = labels.index("O")
 
-    def call():
-        lg, of = O.forward(wav, lang, sd, enc, arch, hc)
-        return O.tags_from_logits(lg, o_id, 0.5)
+    def timed(nb):
+        wav = wav_all[:nb]
+        lang = torch.arange(nb) % cfg["model"]["num_languages"]
 
-    call()                                   # warm-up
-    ts = []
-    for _ in range(calls):
-        t0 = time.perf_counter()
-        call()
-        ts.append(time.perf_counter() - t0)
-    med = float(np.median(ts))
+        def call():
+            lg, of = O.forward(wav, lang, sd, enc, arch, hc)
+            return O.tags_from_logits(lg, o_id, 0.5)
+
+        call()                                   # warm-up
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        return nb * clip_seconds / med, med
+
+    v1, m1 = timed(1)
+    vb, mb = timed(clips)
     return {
-        "value": clips * CLIP_SECONDS / med, "unit": "audio-s/s", "cores": cores, "kind": "port",
-        "sample": f"{calls} calls x {clips} clips x 30 s (same config, fp32, torch CPU, batch {clips}); median call {med:.3f} s",
+        "value": vb, "unit": "audio-s/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+        "sample": f"median of {calls} calls x {clips} clips x {clip_seconds:g} s in one batch (same config, fp32, torch CPU, 1 warm-up call); "
+                  f"median call {mb:.3f} s",
+        "value_batch1": v1,
+        "sample_batch1": f"median of {calls} calls x 1 clip x {clip_seconds:g} s, B = 1 per call like the reference's loop (infer.py:261); "
+                         f"median call {m1:.3f} s",
         "torch_threads": torch.get_num_threads(),
     }
 
@@ -131,6 +164,8 @@ def main():
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    if args.config_index not in CONFIG_SHAPE:
+        raise SystemExit("--config-index must be one of 1, 2, 3, 4")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -140,18 +175,27 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from wfl_asr_amd import synth
-    from wfl_asr_amd.tagger import BIOPhonemeTagger
+    from wfl_asr_amd.tagger import BIOPhonemeTagger, raise_on_status
     from wfl_asr_amd.dist import gather_packed
 
     cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(args.config_index)
+    def_b, def_s = (16, 30.0) if args.full_head else CONFIG_SHAPE[args.config_index]
+    B = args.batch or def_b
+    clip_seconds = args.clip_seconds or def_s
     labels = synth.make_labels(70)
     sd_np = synth.make_state_dict(cfg, len(labels), seed=1)
-    model = BIOPhonemeTagger(cfg, labels)
+    model = BIOPhonemeTagger(cfg, labels, device=dev)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     model.to(dev).eval()
 
-    B, L = args.batch, int(CLIP_SECONDS * SR)
-    wav = torch.from_numpy(synth.make_batch(10000 + rank * B, B, L, seed=1)).to(dev)     # resident in HBM
+    L = int(clip_seconds * SR)
+    # distinct clips for the first 16 rows, the rest are rolled / rescaled copies of them (generating 64 x 30 s in numpy takes
+    # longer than the whole benchmark; every row still differs from every other)
+    n_gen = min(B, 16)
+    base = synth.make_batch(10000 + rank * n_gen, n_gen, L, seed=1)
+    rows = [np.roll(base[i % n_gen], 977 * (i // n_gen)) * (1.0 - 0.03 * (i // n_gen)) for i in range(B)]
+    wav_host = np.stack(rows).astype(np.float32)
+    wav = torch.from_numpy(wav_host).to(dev)                                              # resident in HBM
     lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
     T = model.num_frames(L)
     words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
@@ -165,15 +209,15 @@ def main():
 
     use_graph = args.graph
 
-    def step(graph=use_graph, single=False):
+    def step(graph=use_graph, single=False, x=None):
         slot = 0 if single else step_no[0] % nfl      # single: the kernel-timing pass runs one batch at a time
         step_no[0] += 1
         host_tags = host_bufs[slot]
         with torch.cuda.stream(streams[slot]):
-            out = model.label(wav, lang, threshold=0.5, graph=graph, slot=slot)
+            out = model.label(wav if x is None else x, lang, threshold=0.5, graph=graph, slot=slot)
             if not multi:
                 host_tags[0].copy_(out.packed, non_blocking=True)
-                return
+                return slot
         # N > 1: the forward ran on stream `slot`; the collective and the host copy are issued from ONE separate stream (every
         # RCCL call of this process comes from that stream, in program order), which waits for that forward only, so the next
         # step's forward (other stream) still overlaps
@@ -181,14 +225,20 @@ def main():
         comm.wait_stream(streams[slot])
         out.packed.record_stream(comm)
         with torch.cuda.stream(comm):
-            rows = gather_packed(out.packed, dst=0, out=gather_bufs[slot] if rank == 0 else None)   # ONE collective, no re-packing
+            got = gather_packed(out.packed, dst=0, out=gather_bufs[slot] if rank == 0 else None)   # ONE collective, no re-packing
             if rank == 0:
-                host_tags.copy_(rows, non_blocking=True)
+                host_tags.copy_(got, non_blocking=True)
+        return slot
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def check_status():
+        for hb in host_bufs:                       # every rank's status word of the last step on each slot
+            for r in range(hb.shape[0]):
+                raise_on_status(int(hb[r, words - 1]))
 
     for _ in range(args.warmup):
         step()
@@ -198,9 +248,50 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    check_status()
 
-    # Roofline pass: the same K steps again, launched eagerly with a HIP-event pair around every GEMM launch on the
-    # launch stream (events cannot live inside a replayed graph; the kernels and their inputs are identical).
+    # ---- with-H2D leg: the same K steps, each on a batch that crosses PCIe inside the step
+    h2d = None
+    if not args.no_h2d:
+        n_rot = 8
+        pinned = [torch.from_numpy(np.roll(wav_host, j, axis=0).copy()).pin_memory() for j in range(n_rot)]
+        dev_in = [torch.empty(B, L, dtype=torch.float32, device=dev) for _ in range(nfl + 1)]
+        copy_stream = torch.cuda.Stream(dev)
+        copied = [torch.cuda.Event() for _ in range(nfl + 1)]
+        consumed = [torch.cuda.Event() for _ in range(nfl + 1)]
+
+        def step_h2d(i):
+            k = i % (nfl + 1)
+            slot = step_no[0] % nfl
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[k])                  # the forward that last read this device buffer is done
+                dev_in[k].copy_(pinned[i % n_rot], non_blocking=True)
+                copied[k].record(copy_stream)
+            streams[slot].wait_event(copied[k])
+            step(x=dev_in[k])
+            consumed[k].record(streams[slot])
+
+        for k in range(nfl + 1):
+            consumed[k].record(streams[0])
+        for i in range(args.warmup):
+            step_h2d(i)
+        fence()
+        th = time.perf_counter()
+        for i in range(args.steps):
+            step_h2d(i)
+        fence()
+        el_h = time.perf_counter() - th
+        check_status()
+        if world > 1:
+            t = torch.tensor([el_h], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_h = float(t.item())
+        h2d = {"value_with_h2d": world * B * clip_seconds * args.steps / el_h, "ms_per_step_with_h2d": 1e3 * el_h / args.steps,
+               "h2d_bytes_per_step": B * L * 4, "distinct_host_batches": n_rot}
+        del pinned, dev_in
+
+    # Roofline pass: the same K steps again, launched eagerly with a HIP-event pair around every GEMM / attention / LSTM /
+    # log-mel / LayerNorm launch on the launch stream (events cannot live inside a replayed graph; kernels and inputs are identical).
     use_events = not args.no_kernel_events
     prof = []
     if use_events:
@@ -220,9 +311,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = None
     if rank == 0:
-        audio_s = world * B * CLIP_SECONDS * args.steps
+        audio_s = world * B * clip_seconds * args.steps
         roof = None
         if prof:
             acts = {0: 0, 1: 1, 2: 2, 3: 3}
@@ -239,45 +329,59 @@ def main():
                     return "gemm256_kernel<%d, %s, %s, %d>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
                 return "gemm_bf16_kernel<%d, %s, %s>" % (acts[act], tf(glu), tf(f32))
 
-            tot_ms = sum(p["ms"] for p in prof)
-            tot_fl = sum(p["flops"] for p in prof)
-            tot_n = sum(p["launches"] for p in prof)
-            top = max(prof, key=lambda p: p["ms"])
+            gemm = [p for p in prof if p["key"] < 2040]
+            other = [p for p in prof if p["key"] >= 2040]
+            tot_ms = sum(p["ms"] for p in gemm)
+            tot_fl = sum(p["flops"] for p in gemm)
+            tot_n = sum(p["launches"] for p in gemm)
+            top = max(gemm, key=lambda p: p["ms"])
             traffic = pmc_traffic()
+            breakdown = {"bf16 MFMA GEMM family": tot_ms / args.steps}
+            for p in other:
+                breakdown[OTHER_KEYS.get(p["key"], str(p["key"]))] = p["ms"] / args.steps
             roof = {
                 "bound": "mfma",
                 "kernel": "bf16 MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations)",
-                "timing": "HIP events (launch stream) around every GEMM launch of a second pass over the same %d steps, run "
-                          "right after the timed region, one batch at a time so that no other kernel shares the GPU with the one "
-                          "being timed (%.3f ms/step with the events in)" % (args.steps, eager_ms),
+                "timing": "HIP events (launch stream) around every launch of a second pass over the same %d steps, run right after the "
+                          "timed region, one batch at a time so that no other kernel shares the GPU with the one being timed "
+                          "(%.3f ms/step with the events in)" % (args.steps, eager_ms),
                 "achieved": tot_fl / tot_ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "launches_per_step": tot_n / args.steps, "avg_launch_us": 1e3 * tot_ms / tot_n,
                 "gflop_per_launch": tot_fl / tot_n / 1e9, "gemm_ms_per_step": tot_ms / args.steps,
+                "breakdown_ms_per_step": breakdown,
+                "other_kernels": [{"kernel": OTHER_KEYS.get(p["key"], str(p["key"])), "launches": p["launches"],
+                                   "avg_us": 1e3 * p["ms"] / p["launches"],
+                                   "tflops": (p["flops"] / p["ms"] / 1e9) if p["flops"] else None} for p in other],
                 "variants": [
                     {"kernel": kname(p["key"]), "launches": p["launches"], "avg_us": 1e3 * p["ms"] / p["launches"],
                      "tflops": p["flops"] / p["ms"] / 1e9, "frac": p["flops"] / p["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS}
-                    for p in sorted(prof, key=lambda p: -p["ms"])],
+                    for p in sorted(gemm, key=lambda p: -p["ms"])],
                 "top_variant": {"kernel": kname(top["key"]), "avg_us": 1e3 * top["ms"] / top["launches"],
                                 "tflops": top["flops"] / top["ms"] / 1e9},
             }
+        m = cfg["model"]
+        enc_name = m["whisper_model"] if m["encoder_type"] == "whisper" else m["wavlm_model"]
         result = {
             "metric": "audio_seconds_labeled_per_sec_per_node", "value": audio_s / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("default config.yaml head: " if args.full_head else "BASELINE configs[%d]: " % args.config_index)
-                       + "%s + %s%d Conformer blocks%s, %d x 30 s clips per GPU" % (
-                cfg["model"]["whisper_model"], "2-layer BiLSTM + " if cfg["model"]["enable_bilstm"] else "",
-                cfg["model"]["num_conformer_layers"], " + dilated convs" if cfg["model"]["enable_dilated_conv"] else "", B),
-                "clips_per_gpu": B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": T, "tags": len(labels),
+                       + "%s + %s%d Conformer blocks%s, %d x %g s clips per GPU" % (
+                enc_name, "%d-layer BiLSTM + " % m["bilstm_num_layer"] if m["enable_bilstm"] else "", m["num_conformer_layers"],
+                " + %d dilated convs" % m["dilated_conv_depth"] if m["enable_dilated_conv"] else "", B, clip_seconds),
+                "clips_per_gpu": B, "clip_seconds": clip_seconds, "frames_per_clip": T, "tags": len(labels),
                 "parallelism": f"clip-sharded dp{world}", "launch": "hip graph replay" if use_graph else "eager",
-                       "batches_in_flight": nfl},
+                "batches_in_flight": nfl},
             "roofline": roof,
         }
+        if h2d:
+            result.update(h2d)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, labels, sd_np, args.cpu_clips, args.cpu_calls)
+            clips = args.cpu_clips or (16 if (args.config_index == 1 and not args.full_head) else 4)
+            result["cpu_baseline"] = cpu_baseline(cfg, labels, sd_np, clips, args.cpu_calls, clip_seconds)
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -20,6 +20,7 @@ def tiny_wavlm_config(stable, **kw):
 GOLDEN_CASES = {
     "whisper_tiny": tiny_whisper_config,
     "whisper_base_cfg2": lambda: synth.baseline_config(1),
+    "whisper_base_cfg2_bf16w": lambda: synth.baseline_config(1),     # reference run on the bf16-rounded checkpoint
     "whisper_base_full": lambda: synth.base_config("whisper"),
     "wavlm_base_cfg1": lambda: synth.baseline_config(0),
     "wavlm_tiny_group": lambda: tiny_wavlm_config(False),

@@ -12,6 +12,7 @@ Outputs (all small):
   whisper_tiny.npz        full tensors for a d=64 / 2-layer / 100-frame Whisper + full default head
   whisper_base_cfg2.npz   BASELINE config 2 (Whisper-base + 2 Conformer), B=2 x 30 s: ids, max-prob,
                           offsets, top-2 margin, sparse logits rows, log-mel/hidden samples
+  whisper_base_cfg2_bf16w.npz   the same case with the checkpoint's weight tensors rounded to bf16 first (synth.round_weights_bf16)
   whisper_base_full.npz   Whisper-base + default config.yaml head (BiLSTM x2, Conformer x2, dilated x2)
   wavlm_*.npz             WavLM cases (BASELINE config 1 and a tiny stable-layer-norm variant)
   postprocess.json        outputs of the reference's own host functions on seeded inputs
@@ -89,8 +90,10 @@ def build_reference(config, labels, tmp):
     return m, enc, arch
 
 
-def load_synth(m, config, n_classes, seed):
+def load_synth(m, config, n_classes, seed, bf16_weights=False):
     sd_np = synth.make_state_dict(config, n_classes, seed=seed)
+    if bf16_weights:                      # the reference, unmodified, on the checkpoint with bf16-rounded weight tensors
+        sd_np = synth.round_weights_bf16(sd_np)
     ref_keys = set(m.state_dict().keys())
     mine = set(sd_np.keys())
     assert ref_keys == mine, (sorted(ref_keys - mine)[:10], sorted(mine - ref_keys)[:10])
@@ -99,10 +102,10 @@ def load_synth(m, config, n_classes, seed):
     return sd_np
 
 
-def run_case(name, config, n_phonemes, B, L, seed, tmp, full=False, clip0=0, sine=False, rows=24):
+def run_case(name, config, n_phonemes, B, L, seed, tmp, full=False, clip0=0, sine=False, rows=24, bf16_weights=False):
     labels = synth.make_labels(n_phonemes)
     m, enc, arch = build_reference(config, labels, tmp)
-    load_synth(m, config, len(labels), seed)
+    load_synth(m, config, len(labels), seed, bf16_weights)
     if sine:
         wav = np.stack([synth.sine_clip(L)] * B)
     else:
@@ -125,7 +128,7 @@ def run_case(name, config, n_phonemes, B, L, seed, tmp, full=False, clip0=0, sin
         lang_id=lang, seed=np.int64(seed), clip0=np.int64(clip0), L=np.int64(L), n_phonemes=np.int64(n_phonemes),
         argmax=arg.numpy().astype(np.int16), maxprob=maxp.numpy().astype(np.float32),
         margin=(top2[..., 0] - top2[..., 1]).numpy().astype(np.float32),
-        offsets=offsets.numpy().astype(np.float32),
+        offsets=offsets.numpy().astype(np.float32), bf16_weights=np.int64(int(bf16_weights)),
     )
     T = logits.shape[1]
     if full:
@@ -226,6 +229,10 @@ def main():
             run_case("whisper_tiny", tiny_whisper_config(), 5, B=2, L=24000, seed=11, tmp=tmp, full=True)
         if not which or "cfg2" in which:
             run_case("whisper_base_cfg2", synth.baseline_config(1), 70, B=2, L=480000, seed=1, tmp=tmp, clip0=1000)
+        if not which or "cfg2w" in which:
+            # the same case on the bf16-rounded checkpoint: the target a bf16-WEIGHT deployment is held to with the tight tolerance
+            run_case("whisper_base_cfg2_bf16w", synth.baseline_config(1), 70, B=2, L=480000, seed=1, tmp=tmp, clip0=1000,
+                     bf16_weights=True)
         if not which or "full" in which:
             run_case("whisper_base_full", synth.base_config("whisper"), 70, B=1, L=300000, seed=2, tmp=tmp, clip0=2000)
         if not which or "wavlm" in which:

@@ -1,13 +1,25 @@
 """-m gpu: the whole HIP forward (through wfl_forward) against the golden fixtures (outputs of the reference) and
 against the oracle on the same seeded inputs, plus size-independent properties at BASELINE config-2 size.
 
-Tolerances (bf16 weights/activations with fp32 accumulation vs the fp32 reference), stated once here:
-  log-mel (fp32 path)        |err| <= 2e-3 everywhere, mean |err| <= 1e-4         (near-floor bins are fp32-FFT noise)
-  encoder hidden (LN output) |err| <= 0.08 abs (values are O(1)), mean |err| <= 0.012
-  logits (std ~6.5)          |err| <= 0.6 abs, mean |err| <= 0.08
-  max-prob                   |err| <= 0.10;  offsets |err| <= 0.03
-  tag ids                    identical on every frame whose fp32 top-2 logit margin > TAU = 0.5
-                             and whose max-prob is further than 0.08 from the threshold; >= 60 % of frames qualify (the rest are near-ties or sit at the threshold)
+Tolerances (bf16 MFMA operands with fp32 accumulation; residual stream carried as bf16 hi + lo, classifier in split
+precision), stated once here.  tests/study_quant.py shows where the error comes from on the cfg2 fixture: rounding the WEIGHTS
+to bf16 alone moves the logits by 0.155 max / 0.033 mean (a fixed property of a bf16-weight deployment), activation rounding by
+0.076 / 0.014.  So there are two targets:
+
+  (A) the reference on the checkpoint as given (fp32 weights) -- every fixture except *_bf16w:
+      log-mel (fp32 path)        |err| <= 2e-3 everywhere, mean |err| <= 1e-4       (near-floor bins are fp32-FFT noise)
+      encoder hidden (LN output) |err| <= 0.05 abs (values are O(1)), mean |err| <= 0.008
+      logits (std ~6.5)          |err| <= 0.40 abs, mean |err| <= 0.07
+      max-prob                   |err| <= 0.08;  offsets |err| <= 0.02
+      tag ids                    identical on every frame whose fp32 top-2 logit margin > TAU = 0.4 and whose max-prob is
+                                 further than BAND = 0.06 from the threshold
+  (B) the reference on the bf16-rounded checkpoint (synth.round_weights_bf16; fixture whisper_base_cfg2_bf16w, and the oracle on
+      the rounded weights in the held-out test) -- what is left is activation rounding:
+      logits |err| <= 0.15 abs, mean <= 0.03;  max-prob <= 0.04;  tag ids identical wherever margin > TAU_W = 0.2 and
+      |max-prob - threshold| > BAND_W = 0.03, which must cover >= 80 % of the fixture's frames (measured 83 %); raw argmax
+      mismatches < 1 % (measured 0.87 %: all of them near-ties, 7.9 % of the fixture's frames have a top-2 margin <= 0.2).
+  Models whose logits live on another scale (cfg3's are ~20x smaller) scale TAU with the reference logits' standard deviation:
+  tau = TAU * std / 6.5 (6.5 = the cfg2 fixture's).
 """
 import json
 import os
@@ -24,7 +36,8 @@ from cases import GOLDEN_CASES, tiny_whisper_config
 
 pytestmark = pytest.mark.gpu
 
-TAU = 0.5
+TAU, BAND = 0.4, 0.06
+TAU_W, BAND_W = 0.2, 0.03
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
@@ -60,14 +73,14 @@ def _check_decisions(name, out, ref_logits, ref_offsets, o_id, thr):
     err = (lg - ref_logits).abs()
     mp_err = (out.maxprob.cpu() - maxp_ref).abs()
     of_err = (out.offsets.cpu() - ref_offsets).abs()
-    safe = (margin > TAU) & ((maxp_ref - thr).abs() > 0.08)
+    safe = (margin > TAU) & ((maxp_ref - thr).abs() > BAND)
     arg_bad = int((out.argmax.cpu().long() != arg_ref)[margin > TAU].sum())
     ids_bad = int((out.ids.cpu().long() != ids_ref)[safe].sum())
     _note(name, logits_max=err.max(), logits_mean=err.mean(), maxprob_max=mp_err.max(), offsets_max=of_err.max(),
           safe_frac=safe.float().mean(), argmax_bad=arg_bad, ids_bad=ids_bad,
           argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()), frames=int(arg_ref.numel()))
-    assert err.max() <= 0.6 and err.mean() <= 0.08, (err.max(), err.mean())
-    assert mp_err.max() <= 0.10 and of_err.max() <= 0.03, (mp_err.max(), of_err.max())
+    assert err.max() <= 0.40 and err.mean() <= 0.07, (err.max(), err.mean())
+    assert mp_err.max() <= 0.08 and of_err.max() <= 0.02, (mp_err.max(), of_err.max())
     assert arg_bad == 0 and ids_bad == 0
     assert safe.float().mean() >= 0.60
 
@@ -92,11 +105,20 @@ def test_logmel_matches_oracle():
     assert torch.equal(got, got2)
 
 
-@pytest.mark.parametrize("name", ["whisper_base_cfg2"])
+@pytest.mark.parametrize("name", ["whisper_base_cfg2", "whisper_base_cfg2_bf16w"])
 def test_forward_matches_reference_golden(name, golden_dir):
+    """BASELINE config 2 against outputs of the reference itself: on the checkpoint as given (target A) and on the bf16-rounded
+    checkpoint (target B, tight)."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = GOLDEN_CASES[name]()
-    m, labels, sd_np = _build(cfg, int(g["n_phonemes"]), int(g["seed"]))
+    bf16w = "bf16_weights" in g and bool(int(g["bf16_weights"]))
+    labels = synth.make_labels(int(g["n_phonemes"]))
+    sd_np = synth.make_state_dict(cfg, len(labels), seed=int(g["seed"]))
+    if bf16w:
+        sd_np = synth.round_weights_bf16(sd_np)
+    m = BIOPhonemeTagger(cfg, labels)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.to("cuda").eval()
     B, L = len(g["lang_id"]), int(g["L"])
     wav = synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
     thr = 0.5
@@ -109,16 +131,25 @@ def test_forward_matches_reference_golden(name, golden_dir):
     of_err = np.abs(out.offsets.cpu().numpy() - g["offsets"])
     o_id = labels.index("O")
     ids_ref = np.where(g["maxprob"] < thr, o_id, g["argmax"].astype(np.int64))
-    safe = (g["margin"] > TAU) & (np.abs(g["maxprob"] - thr) > 0.08)
-    arg_bad = int((out.argmax.cpu().numpy() != g["argmax"])[g["margin"] > TAU].sum())
+    tau, band = (TAU_W, BAND_W) if bf16w else (TAU, BAND)
+    safe = (g["margin"] > tau) & (np.abs(g["maxprob"] - thr) > band)
+    arg_bad = int((out.argmax.cpu().numpy() != g["argmax"])[g["margin"] > tau].sum())
     ids_bad = int((out.ids.cpu().numpy() != ids_ref)[safe].sum())
+    raw = int((out.argmax.cpu().numpy() != g["argmax"]).sum())
     _note("golden_" + name, hidden_max=hid_err.max(), hidden_mean=hid_err.mean(), logits_max=lg_err.max(),
-          logits_mean=lg_err.mean(), maxprob_max=mp_err.max(), offsets_max=of_err.max(), safe_frac=safe.mean(),
-          argmax_bad=arg_bad, ids_bad=ids_bad, argmax_all_mismatch=int((out.argmax.cpu().numpy() != g["argmax"]).sum()))
-    assert hid_err.max() <= 0.08 and hid_err.mean() <= 0.012
-    assert lg_err.max() <= 0.6 and lg_err.mean() <= 0.08
-    assert mp_err.max() <= 0.10 and of_err.max() <= 0.03
-    assert arg_bad == 0 and ids_bad == 0 and safe.mean() >= 0.60
+          logits_mean=lg_err.mean(), maxprob_max=mp_err.max(), offsets_max=of_err.max(), tau=tau, band=band, safe_frac=safe.mean(),
+          argmax_bad=arg_bad, ids_bad=ids_bad, argmax_all_mismatch=raw, frames=int(g["argmax"].size))
+    assert arg_bad == 0 and ids_bad == 0
+    if bf16w:
+        assert hid_err.max() <= 0.04 and hid_err.mean() <= 0.005
+        assert lg_err.max() <= 0.15 and lg_err.mean() <= 0.03
+        assert mp_err.max() <= 0.04 and of_err.max() <= 0.01
+        assert safe.mean() >= 0.80 and raw < 0.01 * g["argmax"].size
+    else:
+        assert hid_err.max() <= 0.05 and hid_err.mean() <= 0.008
+        assert lg_err.max() <= 0.40 and lg_err.mean() <= 0.07
+        assert mp_err.max() <= 0.08 and of_err.max() <= 0.02
+        assert safe.mean() >= 0.65
 
 
 def _tiny(**kw):
@@ -139,7 +170,7 @@ def test_tiny_forward_vs_oracle_ragged_batch():
     lg, of, hid = _oracle(cfg, labels, sd_np, wav, lang)
     h_err = (out.hidden.cpu() - hid).abs()
     _note("tiny_hidden", max=h_err.max(), mean=h_err.mean())
-    assert h_err.max() <= 0.08
+    assert h_err.max() <= 0.05
     _check_decisions("tiny_ragged", out, lg, of, labels.index("O"), 0.5)
 
 
@@ -240,15 +271,15 @@ def test_bilstm_base_matches_reference_golden(golden_dir):
     lg_err = np.abs(out.logits.cpu().numpy()[:, r] - g["logits_rows"])
     mp_err = np.abs(out.maxprob.cpu().numpy() - g["maxprob"])
     of_err = np.abs(out.offsets.cpu().numpy() - g["offsets"])
-    safe = (g["margin"] > TAU) & (np.abs(g["maxprob"] - thr) > 0.08)
+    safe = (g["margin"] > TAU) & (np.abs(g["maxprob"] - thr) > BAND)
     o_id = labels.index("O")
     ids_ref = np.where(g["maxprob"] < thr, o_id, g["argmax"].astype(np.int64))
     arg_bad = int((out.argmax.cpu().numpy() != g["argmax"])[g["margin"] > TAU].sum())
     ids_bad = int((out.ids.cpu().numpy() != ids_ref)[safe].sum())
     _note("golden_base_full", logits_max=lg_err.max(), logits_mean=lg_err.mean(), maxprob_max=mp_err.max(),
           offsets_max=of_err.max(), safe_frac=safe.mean(), argmax_bad=arg_bad, ids_bad=ids_bad)
-    assert lg_err.max() <= 0.6 and lg_err.mean() <= 0.08
-    assert mp_err.max() <= 0.10 and of_err.max() <= 0.03
+    assert lg_err.max() <= 0.40 and lg_err.mean() <= 0.07
+    assert mp_err.max() <= 0.08 and of_err.max() <= 0.02
     assert arg_bad == 0 and ids_bad == 0 and safe.mean() >= 0.60
     # batch of 20 clips = 2 clip groups (one partial): clip 0 is bit-identical to the B=1 run
     wav20 = np.concatenate([wav, synth.make_batch(7000, 19, L, seed=3)])
@@ -273,7 +304,7 @@ def test_wavlm_matches_reference_golden(name, golden_dir):
     assert tuple(out.logits.shape) == g["logits"].shape
     h_err = np.abs(out.hidden.cpu().numpy() - g["hidden"])
     _note("wavlm_hidden_" + name, max=h_err.max(), mean=h_err.mean(), ref_abs_mean=np.abs(g["hidden"]).mean())
-    assert h_err.max() <= 0.15 and h_err.mean() <= 0.02
+    assert h_err.max() <= 0.08 and h_err.mean() <= 0.012
     _check_decisions(name, out, torch.from_numpy(g["logits"]), torch.from_numpy(g["offsets"]), labels.index("O"), 0.5)
     again = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True)
     assert torch.equal(again.logits, out.logits)
@@ -293,16 +324,17 @@ def test_baseline_configs_3_and_4_vs_oracle(idx, B, L):
     lg, of, hid = _oracle(cfg, labels, sd_np, wav, lang)
     h_err = (out.hidden.cpu() - hid).abs()
     _note(f"cfg{idx + 1}_hidden", max=h_err.max(), mean=h_err.mean())
-    assert h_err.max() <= 0.25 and h_err.mean() <= 0.03
+    assert h_err.max() <= 0.08 and h_err.mean() <= 0.012
     ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
     err = (out.logits.cpu() - lg).abs()
-    safe = margin > 2 * float(err.max())
+    tau = TAU * float(lg.std()) / 6.5
+    safe = margin > tau
     bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
-    _note(f"cfg{idx + 1}", logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
+    _note(f"cfg{idx + 1}", logit_std=lg.std(), tau=tau, logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
           safe_frac=safe.float().mean(), argmax_bad=bad, argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()),
           frames=int(arg_ref.numel()))
-    assert err.max() <= 1.0 and err.mean() <= 0.12          # deeper stacks (12-24 encoder layers): looser than cfg2
-    assert (out.offsets.cpu() - of).abs().max() <= 0.05
+    assert err.max() <= 0.40 and err.mean() <= 0.08
+    assert (out.offsets.cpu() - of).abs().max() <= 0.02
     assert bad == 0 and safe.float().mean() >= 0.5
 
 
@@ -321,15 +353,16 @@ def test_baseline_config_5_width_vs_oracle():
     lg, of, hid = _oracle(cfg, labels, sd_np, wav, lang)
     h_err = (out.hidden.cpu() - hid).abs()
     _note("cfg5_hidden", max=h_err.max(), mean=h_err.mean())
-    assert h_err.max() <= 0.25 and h_err.mean() <= 0.03
+    assert h_err.max() <= 0.08 and h_err.mean() <= 0.012
     ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
     err = (out.logits.cpu() - lg).abs()
-    safe = margin > 2 * float(err.max())
+    tau = TAU * float(lg.std()) / 6.5
+    safe = margin > tau
     bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
-    _note("cfg5", logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
+    _note("cfg5", logit_std=lg.std(), tau=tau, logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
           safe_frac=safe.float().mean(), argmax_bad=bad, frames=int(arg_ref.numel()))
-    assert err.max() <= 1.0 and err.mean() <= 0.12
-    assert (out.offsets.cpu() - of).abs().max() <= 0.05
+    assert err.max() <= 0.40 and err.mean() <= 0.08
+    assert (out.offsets.cpu() - of).abs().max() <= 0.02
     assert bad == 0 and safe.float().mean() >= 0.5
 
 

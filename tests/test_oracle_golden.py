@@ -20,7 +20,10 @@ def _run(name, golden_dir):
     cfg = GOLDEN_CASES[name]()
     labels = synth.make_labels(int(g["n_phonemes"]))
     enc, arch = resolve_encoder_arch(cfg["model"])
-    sd = O.to_torch_state_dict(synth.make_state_dict(cfg, len(labels), seed=int(g["seed"])))
+    sd_np = synth.make_state_dict(cfg, len(labels), seed=int(g["seed"]))
+    if "bf16_weights" in g and int(g["bf16_weights"]):
+        sd_np = synth.round_weights_bf16(sd_np)
+    sd = O.to_torch_state_dict(sd_np)
     B, L = len(g["lang_id"]), int(g["L"])
     if name == "wavlm_base_cfg1":
         wav = np.stack([synth.sine_clip(L)] * B)

@@ -45,6 +45,12 @@ struct GemmArgs {
   int clip_ld;
   const bf16_t* res;        // residual, same row mapping as C, or null
   long ldres;
+  // The residual stream is carried as a bf16 PAIR hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits), so that the
+  // dozens of residual adds of a forward do not each round the running sum to 8 bits.  GEMM operands read `hi` only -- exactly
+  // the bf16 rounding of x an MFMA operand is anyway.  Both optional:
+  const bf16_t* res_lo;     //   low half of the residual (ld = ldres), null: the residual is hi alone
+  bf16_t* c_lo;             //   low half of the output (bf16 outputs only; ld = ldc, same row mapping as C), null: not kept
+  int acc_f32;              // out_f32 only: C += result (the split-precision classifier adds its passes up in fp32)
   float alpha;              // out = res + alpha * act(v)
   const bf16_t* pos;        // [T][ldpos] added after the activation (positional table) or null
   long ldpos;

@@ -256,10 +256,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   }
   // Unconditional loads (a branch per load would make hipcc wait vmcnt(0) after each): rows that are not stored
   // are halo / tail rows of the residual's frame-row buffer, which exist; the positional row is clamped.
-  bf16x8 rr[NP], pp[NP];
+  bf16x8 rr[NP], rl[NP], pp[NP];
   if (p.res) {
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) rr[pass] = *(const bf16x8*)(p.res + orow[pass] * p.ldres + nb);
+    if (p.res_lo) {                                   // residual stream carried as hi + lo (common.h)
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) rl[pass] = *(const bf16x8*)(p.res_lo + orow[pass] * p.ldres + nb);
+    }
   }
   if (p.pos) {
 #pragma unroll
@@ -282,11 +286,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
       for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[pass][e]);
     }
     if (p.res) {
+      if (p.res_lo) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[pass][e]) + p.alpha * v[e];
+        for (int e = 0; e < 8; ++e) v[e] = (bf2f(rr[pass][e]) + bf2f(rl[pass][e])) + p.alpha * v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[pass][e]) + p.alpha * v[e];
+      }
     }
     if (OUTF32) {
       float* o = (float*)p.C + orow[pass] * p.ldc + nb;
+      if (p.acc_f32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (nb + e < nvalid) v[e] += o[e];
+      }
       if (nb + 8 <= nvalid && (p.ldc & 3) == 0) {
         *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
         *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -300,11 +314,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
       *(bf16x8*)((bf16_t*)p.C + orow[pass] * p.ldc + nb) = o;
+      if (p.c_lo) {
+        bf16x8 ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ol[e] = f2bf(v[e] - bf2f(o[e]));
+        *(bf16x8*)(p.c_lo + orow[pass] * p.ldc + nb) = ol;
+      }
     } else {
       bf16_t* o = (bf16_t*)p.C + orow[pass] * p.ldc + nb;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (nb + e < nvalid) o[e] = f2bf(v[e]);
+        if (nb + e < nvalid) {
+          o[e] = f2bf(v[e]);
+          if (p.c_lo) p.c_lo[orow[pass] * p.ldc + nb + e] = f2bf(v[e] - bf2f(o[e]));
+        }
     }
   }
   STAMP(4);

@@ -263,11 +263,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
       constexpr int GP = NP < 4 ? NP : 4;
 #pragma unroll
       for (int g0 = 0; g0 < NP; g0 += GP) {
-        bf16x8 rr[GP];
+        bf16x8 rr[GP], rl[GP];
         if (p.res) {
 #pragma unroll
           for (int q = 0; q < GP; ++q)
             if (g0 + q < NP) rr[q] = *(const bf16x8*)(p.res + orow[g0 + q] * p.ldres + nb);
+          if (p.res_lo) {                             // residual stream carried as hi + lo (common.h)
+#pragma unroll
+            for (int q = 0; q < GP; ++q)
+              if (g0 + q < NP) rl[q] = *(const bf16x8*)(p.res_lo + orow[g0 + q] * p.ldres + nb);
+          }
         }
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
@@ -288,11 +293,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[e]);
           }
           if (p.res) {
+            if (p.res_lo) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[q][e]) + p.alpha * v[e];
+              for (int e = 0; e < 8; ++e) v[e] = (bf2f(rr[q][e]) + bf2f(rl[q][e])) + p.alpha * v[e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = bf2f(rr[q][e]) + p.alpha * v[e];
+            }
           }
           if (OUTF32) {
             float* o = (float*)p.C + orow[pass] * p.ldc + nb;
+            if (p.acc_f32) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (nb + e < nvalid) v[e] += o[e];
+            }
             if (nb + 8 <= nvalid && (p.ldc & 3) == 0) {
               *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
               *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -306,11 +321,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
             *(bf16x8*)((bf16_t*)p.C + orow[pass] * p.ldc + nb) = o;
+            if (p.c_lo) {
+              bf16x8 ol;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ol[e] = f2bf(v[e] - bf2f(o[e]));
+              *(bf16x8*)(p.c_lo + orow[pass] * p.ldc + nb) = ol;
+            }
           } else {
             bf16_t* o = (bf16_t*)p.C + orow[pass] * p.ldc + nb;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-              if (nb + e < nvalid) o[e] = f2bf(v[e]);
+              if (nb + e < nvalid) {
+                o[e] = f2bf(v[e]);
+                if (p.c_lo) p.c_lo[orow[pass] * p.ldc + nb + e] = f2bf(v[e] - bf2f(o[e]));
+              }
           }
         }
       }

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #endif
   constexpr int AEXT = 224 * SBK * 2;             // CONV: extended frame tile (BMV + up to 32 taps - 1 rows), two of them
   constexpr int AOFF = SNST * STB;
-  constexpr int NSTORE = 2 * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around)
+  constexpr int NSTORE = (RES ? 4 : 2) * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around; a residual
+                                                                  // launch always stores the hi and the lo half)
   constexpr int SROW = 4;                             // float2 slots per row of the statistics buffer (one per 256-column tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* stat_lds = (float*)(smem + SNST * STB + (CONV ? 2 * AEXT : 0));  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
@@ -230,14 +231,23 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       if (t >= p.P) { t -= p.P; ++b; }
       orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * p.c_pitch + t : -1;
     }
-    bf16x8 rr[RES ? MT : 1][2];
+    // residual hi + lo halves: a ring of three 16-frame tiles in flight (all six at once would not fit the register file next
+    // to the accumulators); tile u + 3 is requested as soon as tile u has been consumed
+    constexpr int RING = 3;
+    bf16x8 rr[RES ? RING : 1][2], rl[RES ? RING : 1][2];
+    const bf16_t* res_lo = p.res_lo ? p.res_lo : p.res;     // no low half: read the high one again and scale it away
+    const float lo_scale = p.res_lo ? 1.f : 0.f;
+    auto load_res = [&](int u, int slot) __attribute__((always_inline)) {
+      const long r = orow[u] >= 0 ? orow[u] : p.c_lead;     // any valid row: the value is never stored
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        rr[slot][h] = *(const bf16x8*)(p.res + r * p.ldres + nb + 32 * h);
+        rl[slot][h] = *(const bf16x8*)(res_lo + r * p.ldres + nb + 32 * h);
+      }
+    };
     if (RES) {
 #pragma unroll
-      for (int u = 0; u < MT; ++u) {
-        const long r = orow[u] >= 0 ? orow[u] : p.c_lead;   // any valid row: the value is never stored
-#pragma unroll
-        for (int h = 0; h < 2; ++h) rr[u][h] = *(const bf16x8*)(p.res + r * p.ldres + nb + 32 * h);
-      }
+      for (int u = 0; u < RING && u < MT; ++u) load_res(u, u);
     }
     float mu[LNF ? MT : 1], rs[LNF ? MT : 1];
     if (LNF == 1) {
@@ -286,15 +296,24 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             float v = acc[u][2 * h + q][e];
             if (LNF) v = (v - mu[u] * sj[2 * h + q][e]) * rs[u];
             v = apply_act<ACT>(v + bj[2 * h + q][e]);
-            if (RES) v = bf2f(rr[u][h][4 * q + e]) + p.alpha * v;
+            if (RES) v = (bf2f(rr[u % RING][h][4 * q + e]) + lo_scale * bf2f(rl[u % RING][h][4 * q + e])) + p.alpha * v;
             x[4 * q + e] = v;
           }
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(x[e]);
+        const bool keep = orow[u] >= 0 && nb + 32 * h < p.n_valid;
         char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
-        dst = (orow[u] >= 0 && nb + 32 * h < p.n_valid) ? dst : trash;
+        dst = keep ? dst : trash;
         *(bf16x8*)dst = o;
+        if (RES) {                                   // low half: what the bf16 rounding of the sum left behind
+          bf16x8 ol;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ol[e] = f2bf(x[e] - bf2f(o[e]));
+          char* dl = (char*)(p.c_lo + (long)orow[u] * p.ldc + nb + 32 * h);
+          dl = (keep && p.c_lo) ? dl : trash;
+          *(bf16x8*)dl = ol;
+        }
         if (STATS) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) { const float r = bf2f(o[e]); t1 += r; t2 = fmaf(r, r, t2); }
@@ -308,6 +327,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (RES && u + RING < MT) load_res(u + RING, u % RING);
     }
     if (STATS) {
       // The last of the group's four waves to get here adds the four partials of every row in a fixed order (bit-exact
@@ -525,6 +545,7 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   return false;
 #endif
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
+  if (a.c_lo && !a.res) return false;                 // only the residual epilogue here keeps a low half (gemm256 / gemm do it for any)
   if (a.N % 256 || a.K % SBK || a.cin % SBK || a.K / SBK < 8 || a.n_valid % 8) return false;
   // (no lower bound on M: a LayerNorm folded through the producer's statistics must not depend on the batch size -- a clip
   // labelled alone has to equal the same clip inside a batch bit for bit)

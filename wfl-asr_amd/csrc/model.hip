@@ -64,7 +64,7 @@ int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, i
                            const float* b8, const float* cst, float* gate, hipStream_t s);
 int wfl_launch_relpos_table(const float* rel_emb, const int* bucket_of_delta, int max_t, int heads, int T, float* table, hipStream_t s);
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
-                             int B, int P, int T, int C, int gelu, hipStream_t s);
+                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo = nullptr, bf16_t* y_lo = nullptr);
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
@@ -172,6 +172,7 @@ struct wfl_model {
   std::vector<ConfLayer> conf;
   std::vector<Lin> dil;
   Lin cls, off1;
+  Lin cls_lo, cls_hi2;             // split-precision classifier: W - bf16(W), and [bf16(W) | bf16(W)] for the [hi | lo] input taps
   float *off_w2 = nullptr, *off_b2 = nullptr;
   // profiling
   bool prof_on = false;
@@ -686,6 +687,25 @@ static int finalize_head(wfl_model* m, Packer& P) {
       m->dil.push_back(P.conv("dilated_conv_stack." + std::to_string(2 * i), d, d, a.dilated_kernel));
   }
   m->cls = P.linear("classifier", a.num_classes, d);
+  // The classifier runs in split precision (its inputs are the residual stream's hi + lo halves, its weights hi + lo):
+  // logits = [h_hi | h_lo] . [W_hi | W_hi]^T + h_hi . W_lo^T + b, three bf16 MFMA passes summed in fp32 -- 0.4 % of the forward's FLOPs
+  // for a logit error a plain bf16 pass would double (tests/study_quant.py).
+  if (const HostTensor* cw = P.get("classifier.weight", {a.num_classes, d})) {
+    std::vector<float> lo((size_t)a.num_classes * d), hi2((size_t)a.num_classes * 2 * d);
+    for (int n = 0; n < a.num_classes; ++n)
+      for (int k = 0; k < d; ++k) {
+        const float w = cw->data[(size_t)n * d + k];
+        const uint32_t u = (uint32_t)f32_to_bf16_bits(w) << 16;
+        float wh;
+        memcpy(&wh, &u, 4);
+        lo[(size_t)n * d + k] = w - wh;
+        hi2[(size_t)n * 2 * d + k] = wh;
+        hi2[(size_t)n * 2 * d + d + k] = wh;
+      }
+    const HostTensor* cb = P.get("classifier.bias", {a.num_classes});
+    m->cls_lo = P.pack(lo, a.num_classes, d, nullptr);
+    if (cb) m->cls_hi2 = P.pack(hi2, a.num_classes, 2 * d, &cb->data);
+  }
   m->off1 = P.conv("boundary_offset_head.0", d, d, 3);
   const HostTensor* w2 = P.get("boundary_offset_head.2.weight", {2, d, 1});
   const HostTensor* b2 = P.get("boundary_offset_head.2.bias", {2});
@@ -749,7 +769,7 @@ struct Plan {
   long Rl[8];
   // byte offsets
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
-  long FA, FB, XG, gate, rtab, wstats, cstats, err, total;
+  long FA, FB, XG, gate, rtab, wstats, cstats, err, Xlo, Ylo, total;
 };
 
 static int wavlm_frames(const wfl_arch& a, int L) {
@@ -806,6 +826,8 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   }
   p.X = take(p.R * p.d * 2);
   p.Y = take(p.R * p.d * 2);
+  p.Xlo = take(p.R * p.d * 2);                          // low halves of the residual stream (GemmArgs::res_lo)
+  p.Ylo = take(p.R * p.d * 2);
   p.ATT = take(p.R * p.d * 2);
   p.QK = take(p.R * 3 * p.d * 2);                   // packed q | k | v rows
   p.FF = take(p.R * p.ffw * 2);
@@ -848,6 +870,24 @@ struct Runner {
   int rc = 0;
 
   bf16_t* buf(long off) const { return (bf16_t*)(ws + off); }
+  // Residual stream hi + lo (common.h, GemmArgs::res_lo): X and Y have low halves; lo_ok says whether the low half of the
+  // tensor currently held in X / Y is valid (a kernel that writes only the high half invalidates it).
+  bool lo_ok[2] = {false, false};
+  int lo_idx(const void* ptr) const {               // 0: inside X's first row (a column offset is allowed), 1: Y, else -1
+    const long dx = (const char*)ptr - (ws + p.X), dy = (const char*)ptr - (ws + p.Y);
+    if (dx >= 0 && dx < (long)p.d * 2) return 0;
+    if (dy >= 0 && dy < (long)p.d * 2) return 1;
+    return -1;
+  }
+  bf16_t* lo_of(const void* ptr) const {
+    const int i = lo_idx(ptr);
+    if (i < 0) return nullptr;
+    return (bf16_t*)(ws + (i == 0 ? p.Xlo : p.Ylo) + ((const char*)ptr - (ws + (i == 0 ? p.X : p.Y))));
+  }
+  const bf16_t* lo_in(const void* ptr) const { const int i = lo_idx(ptr); return (i >= 0 && lo_ok[i]) ? lo_of(ptr) : nullptr; }
+  bool next_lo_out = false;     // the next gemm() produces a residual-stream tensor: keep its low half
+  bool next_acc_f32 = false;    // the next gemm() (fp32 output) adds to what is there
+  double next_flops = -1.0;     // >= 0: algorithmic FLOPs to book for the next gemm() instead of 2 M N K
   // LayerNorm statistics left behind by the last residual GEMM (gemm_stream.hip, STATS): valid for the rows of `stats_for`
   const void* stats_for = nullptr;
   int stats_nsl = 0;
@@ -872,6 +912,13 @@ struct Runner {
     g.res = res; g.ldres = ldres; g.alpha = alpha;
     g.pos = pos; g.ldpos = ldpos;
     g.act = act; g.glu = glu ? 1 : 0; g.out_f32 = out_f32 ? 1 : 0;
+    g.acc_f32 = (out_f32 && next_acc_f32) ? 1 : 0;
+    if (!out_f32 && !glu && (res || next_lo_out)) g.c_lo = lo_of(C);
+    if (res) g.res_lo = lo_in(res);
+    { const int ci = out_f32 ? -1 : lo_idx(C); if (ci >= 0) lo_ok[ci] = g.c_lo != nullptr; }
+    const double flops_booked = next_flops;
+    next_lo_out = next_acc_f32 = false;
+    next_flops = -1.0;
     if (C == stats_for) stats_for = nullptr;                       // the rows they describe are being overwritten
     if (res && !out_f32 && !glu && act == WFL_ACT_NONE && ldc == p.d && W.n_valid == p.d && c_lead == p.lead && c_pitch == p.P &&
         P == p.P && ln_fold_mode() == 1) {
@@ -897,7 +944,7 @@ struct Runner {
                       ((g.ln_s ? (g.stats_in ? 2 : 1) : 0) << 8) | (g.stats_out ? 1024 : 0);
       m->prof.key.push_back(key);
       m->prof.launches[key] += 1;
-      m->prof.flops[key] += 2.0 * (double)(M / P) * T * (double)W.n_valid * (double)W.K;
+      m->prof.flops[key] += flops_booked >= 0.0 ? flops_booked : 2.0 * (double)(M / P) * T * (double)W.n_valid * (double)W.K;
     }
     if (r) rc = fail(r, "gemm launch failed (" + std::to_string(r) + ")");
   }
@@ -929,11 +976,40 @@ struct Runner {
     gemm(scratch + (long)p.lead * p.d, p.d, plain, M, p.P, p.T, C, ldc, p.lead, p.P, act);
   }
 
-  void ln(const bf16_t* x, bf16_t* y, const LNp& w) {
+  // lo_out: the output is (or may become) a residual-stream tensor -- keep its low half; the input's low half is read when valid
+  void ln(const bf16_t* x, bf16_t* y, const LNp& w, bool lo_out = false) {
     if (rc) return;
     if (y == stats_for) stats_for = nullptr;
-    const int r = wfl_launch_layernorm(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, s);
+    const bf16_t* x_lo = lo_in(x);
+    bf16_t* y_lo = lo_out ? lo_of(y) : nullptr;
+    { const int yi = lo_idx(y); if (yi >= 0) lo_ok[yi] = y_lo != nullptr; }
+    prof_begin();
+    const int r = wfl_launch_layernorm_act(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, 0, s, x_lo, y_lo);
+    prof_end(2043, 0.0);
     if (r) rc = fail(r, "layernorm launch failed");
+  }
+
+  // Timing hook for the non-GEMM kernel families (keys 2040 attention, 2041 BiLSTM recurrence, 2042 log-mel, 2043 LayerNorm)
+  hipEvent_t prof_e1 = nullptr;
+  void prof_begin() {
+    prof_e1 = nullptr;
+    if (!m->prof_on || rc) return;
+    if (m->prof_used >= m->prof.ev.size()) {
+      hipEvent_t a_, b_;
+      if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) { rc = fail(-10, "hipEventCreate"); return; }
+      m->prof.ev.push_back({a_, b_});
+    }
+    (void)hipEventRecord(m->prof.ev[m->prof_used].first, s);
+    prof_e1 = m->prof.ev[m->prof_used].second;
+    ++m->prof_used;
+  }
+  void prof_end(int key, double flops) {
+    if (!prof_e1) return;
+    (void)hipEventRecord(prof_e1, s);
+    m->prof.key.push_back(key);
+    m->prof.launches[key] += 1;
+    m->prof.flops[key] += flops;
+    prof_e1 = nullptr;
   }
 
   void attn(int heads, const float* bias = nullptr, const float* gate = nullptr) {
@@ -942,7 +1018,9 @@ struct Runner {
     a.bias = bias; a.gate = gate;
     a.QK = buf(p.QK); a.ldqk = 3 * p.d; a.lead = p.lead; a.V = buf(p.QK) + 2 * p.d; a.ldv = 3 * p.d; a.O = buf(p.ATT); a.ldo = p.d;
     a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = p.d;
+    prof_begin();
     const int r = wfl_launch_attention(a, s);
+    prof_end(2040, 4.0 * (double)p.B * p.T * (double)p.T * (double)p.d);
     if (r) rc = fail(r, "attention launch failed (" + std::to_string(r) + "; head_dim " + std::to_string(p.d / heads) + ")");
   }
 
@@ -1022,13 +1100,16 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
   bf16_t *X = R.buf(p.X), *Y = R.buf(p.Y), *ATT = R.buf(p.ATT), *QK = R.buf(p.QK), *FF = R.buf(p.FF);
   if (a.encoder_type == WFL_ENC_WHISPER) {
     // ---- Whisper encoder (HF modeling_whisper.py:618-642)
+    R.prof_begin();
     const int r = run_logmel(m, p, R.ws, wav, ldw, lens, nullptr, R.s);
+    R.prof_end(2042, 0.96e9 * (double)B * (a.n_mels / 80.0));
     if (r) return fail(r, "logmel launch failed");
     bf16_t* mel = R.buf(p.mel);
     bf16_t* c1 = R.buf(p.c1);
     // conv1 k3 p1: frame t reads mel rows t-1..t+1 = 3*n_mels contiguous channels
     R.gemm(mel + (long)(p.lead2 - 1) * a.n_mels, a.n_mels, m->conv1, B * p.P2, p.P2, p.T2, c1, d, p.lead2, p.P2, WFL_ACT_GELU);
     // conv2 k3 s2 p1: frame t reads c1 rows 2t-1..2t+1; pitch(c1) = 2 * pitch(X) makes it one flat GEMM with lda = 2d
+    R.next_lo_out = true;                            // the residual stream starts here
     R.gemm(c1 + (long)(p.lead2 - 1) * d, 2 * d, m->conv2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0,
            1.f, 0, 0, false, false, m->pos, d);
     for (int i = 0; i < a.enc_layers; ++i) {
@@ -1039,7 +1120,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       R.ln_gemm(X, Y, L_.ln2, L_.fc1, L_.fc1_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
     }
-    R.ln(X, Y, m->enc_ln);       // encoder output in Y
+    R.ln(X, Y, m->enc_ln, true);   // encoder output in Y (with lang_id None it is the head's residual stream)
   } else {
     // ---- WavLM (HF modeling_wavlm.py:1032-1088).  `lens` is not supported: the reference never pads WavLM input.
     if (lens) return fail(-1, "wfl_forward: per-clip lengths are not supported with the WavLM encoder (batch clips of equal length)");
@@ -1083,6 +1164,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       const int r = wfl_launch_layernorm_act(feats, C, feats, C, m->fp_ln.g, m->fp_ln.b, 1e-5f, p.lead, B, p.P, p.T, C, 0, R.s);
       if (r) return fail(r, "layernorm launch failed");
     }
+    R.next_lo_out = true;
     R.gemm(feats + (long)p.lead * C, C, m->fp_proj, (int)Mrows, p.P, p.T, X, d, p.lead, p.P);
     // positional conv: x + GELU(grouped conv k, pad k/2, last step dropped), one contiguous-tap GEMM per group
     {
@@ -1098,7 +1180,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     }
     bf16_t *H = Y, *S = X;                             // current hidden states / scratch
     const bool stable = a.wavlm_stable_layer_norm != 0;
-    if (!stable) { R.ln(H, S, m->wenc_ln); std::swap(H, S); }
+    if (!stable) { R.ln(H, S, m->wenc_ln, true); std::swap(H, S); }
     float* gate = (float*)(R.ws + p.gate);
     float* rtab = (float*)(R.ws + p.rtab);
     if (!R.rc) {
@@ -1124,16 +1206,18 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       } else {
         // x = LN(x + attn); x = LN_final(x + FFN(x))
         R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
-        R.ln(S, H, L_.ln1);
+        R.ln(S, H, L_.ln1, true);
         R.gemm(H + (long)p.lead * d, d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
         R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
-        R.ln(S, H, L_.ln2);
+        R.ln(S, H, L_.ln2, true);
       }
     }
-    if (stable) { R.ln(H, S, m->wenc_ln); std::swap(H, S); }
+    if (stable) { R.ln(H, S, m->wenc_ln, true); std::swap(H, S); }
     if (H != Y && !R.rc) {                             // the head expects the encoder output in Y
       R.stats_for = nullptr;
       if (wfl_launch_copy16(Y, H, p.R * d * 2, R.s)) return fail(-3, "copy launch failed");
+      if (R.lo_in(H) && wfl_launch_copy16(R.lo_of(Y), R.lo_of(H), p.R * d * 2, R.s)) return fail(-3, "copy launch failed");
+      R.lo_ok[1] = R.lo_in(H) != nullptr;
     }
   }
   return R.rc;
@@ -1172,6 +1256,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
         if (fr) return fail(fr, "fill launch failed");
         idx = lang_dev;
       }
+      R.next_lo_out = true;
       R.gemm(ENC + (long)p.lead * d, d, m->lang, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0,
              false, false, nullptr, 0, m->lang_table, idx, d);
       H = X; S = Y;
@@ -1188,7 +1273,10 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
         la.B = B; la.T = p.T; la.P = p.P; la.H = Hh; la.U = m->lstm_U;
         la.error = (unsigned*)(R.ws + p.err);
         R.stats_for = nullptr;
+        { const int si = R.lo_idx(S); if (si >= 0) R.lo_ok[si] = false; }     // the recurrence writes plain bf16 rows
+        R.prof_begin();
         const int lr = wfl_launch_lstm(la, R.ws + p.lstm_x, R.s);
+        R.prof_end(2041, 2.0 * (double)B * p.T * 2.0 * 4.0 * (double)Hh * (double)Hh);
         if (lr) return fail(lr, lr == -5 ? "BiLSTM: hidden size too large (more than 64 slice workgroups per direction)"
                                           : "lstm launch failed (" + std::to_string(lr) + ")");
         std::swap(H, S);
@@ -1203,7 +1291,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
       R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
       R.attn(a.conformer_heads);
       R.gemm(ATT + (long)p.lead * d, d, C.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
-      R.ln(S, H, C.ln1);
+      R.ln(S, H, C.ln1, true);
       // x = x + pw2(GELU(BN(conv_k(GLU(pw1(LN2(x)))))))
       R.ln(H, S, C.ln2);
       R.gemm(S + (long)p.lead * d, d, C.pw1, (int)Mrows, p.P, p.T, ATT, d, p.lead, p.P, WFL_ACT_NONE, nullptr, 0, 1.f, 0, 0, true);
@@ -1224,8 +1312,19 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
       }
     }
     float* lg_pass = (n_pass > 1 && pass > 0) ? (float*)(R.ws + p.logits2) : lg;
-    R.gemm(H + (long)p.lead * d, d, m->cls, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f, 0,
-           0, false, true);
+    // classifier in split precision: h_hi . W_lo^T first, then [h_hi | h_lo] . [W_hi | W_hi]^T + b added to it in fp32 (the two
+    // input halves are taps one buffer apart; without a valid low half the second pass is the plain K = d one)
+    R.next_flops = 0.0;
+    R.gemm(H + (long)p.lead * d, d, m->cls_lo, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f,
+           0, 0, false, true);
+    R.next_acc_f32 = true;
+    R.next_flops = 2.0 * (double)B * p.T * (double)a.num_classes * (double)d;
+    if (const bf16_t* hlo = R.lo_in(H))
+      R.gemm(H + (long)p.lead * d, d, m->cls_hi2, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0,
+             1.f, d, (long)(hlo - H), false, true);
+    else
+      R.gemm(H + (long)p.lead * d, d, m->cls, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f,
+             0, 0, false, true);
     R.gemm(H + (long)(p.lead - 1) * d, d, m->off1, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0, 1.f, d, d);
     if (R.rc) return R.rc;
     TagArgs t{};

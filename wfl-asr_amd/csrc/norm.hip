@@ -9,7 +9,8 @@ template <int NCH, bool GELU>   // 16-byte chunks per lane (C <= NCH * 512); GEL
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                         long ldy, const float* __restrict__ gam,
                                                         const float* __restrict__ bet, float eps, long lead, int B, int P,
-                                                        int T, int C) {
+                                                        int T, int C, const bf16_t* __restrict__ x_lo, bf16_t* __restrict__ y_lo) {
+  // x_lo / y_lo: the low halves of a residual-stream tensor carried as hi + lo (common.h, GemmArgs::res_lo); both optional
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // index over B*T valid rows
   if (r >= (long)B * T) return;
@@ -23,8 +24,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     const int c0 = (i * 64 + lane) * 8;
     if (c0 < C) {
       const bf16x8 a = *(const bf16x8*)(xp + c0);
+      if (x_lo) {
+        const bf16x8 al = *(const bf16x8*)(x_lo + row * ldx + c0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(a[e]); sum += v[i][e]; }
+        for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(a[e]) + bf2f(al[e]); sum += v[i][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(a[e]); sum += v[i][e]; }
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     if (c0 < C) {
       const f32x4 g0 = *(const f32x4*)(gam + c0), g1 = *(const f32x4*)(gam + c0 + 4);
       const f32x4 b0 = *(const f32x4*)(bet + c0), b1 = *(const f32x4*)(bet + c0 + 4);
-      bf16x8 o;
+      bf16x8 o, ol;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y0 = (v[i][e] - mean) * rstd * g0[e] + b0[e];
@@ -60,36 +67,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
         if (GELU) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); }
         o[e] = f2bf(y0);
         o[4 + e] = f2bf(y1);
+        ol[e] = f2bf(y0 - bf2f(o[e]));
+        ol[4 + e] = f2bf(y1 - bf2f(o[4 + e]));
       }
       *(bf16x8*)(yp + c0) = o;
+      if (y_lo) *(bf16x8*)(y_lo + row * ldy + c0) = ol;
     }
   }
 }
 
 template <bool GELU>
 static int launch_ln(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead, int B,
-                     int P, int T, int C, hipStream_t s) {
+                     int P, int T, int C, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo) {
   const long rows = (long)B * T;
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (C <= 512)
-    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo);
   else if (C <= 1024)
-    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo);
   else
-    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C);
+    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
-                             int B, int P, int T, int C, int gelu, hipStream_t s) {
+                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo) {
   if (C % 8 || ldx % 8 || ldy % 8 || C > 2048) return -1;
-  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s)
-              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s);
+  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo)
+              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo);
 }
 
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
                          long lead, int B, int P, int T, int C, hipStream_t s) {
-  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s);
+  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s, nullptr, nullptr);
 }
 
 // Zero every row that is not a valid frame: [0, lead), each clip's [T, P), and `tail_rows` rows behind the last

@@ -208,6 +208,25 @@ def make_state_dict(config: dict, num_classes: int, seed: int = 0, cls_gain: flo
     return out
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32; NaN/inf pass through."""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    u = a.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return np.where(np.isfinite(a), r, a).astype(np.float32)
+
+
+def round_weights_bf16(sd_np):
+    """The "bf16 checkpoint" of a state dict: every float tensor with two or more dimensions (Linear / Conv / embedding
+    weights -- what the MI355X path keeps in bf16) rounded to bfloat16 and stored back as float32; biases, norm parameters
+    and BatchNorm statistics untouched.  The reference run on THIS checkpoint is the apples-to-apples target for a bf16-weight
+    deployment: what is left between the two is activation rounding only (tests/golden/*_bf16w.npz)."""
+    out = OrderedDict()
+    for k, v in sd_np.items():
+        out[k] = bf16_round(v) if (v.dtype == np.float32 and v.ndim >= 2) else v
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # synthetic clips (SURVEY.md §8d)
 # --------------------------------------------------------------------------------------
