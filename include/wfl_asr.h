@@ -207,6 +207,14 @@ int32_t wfl_host_load_wav(const char* path, float* out, int64_t cap, int32_t* n_
 int32_t wfl_host_load_wavs(const char* const* paths, int32_t n, float* out, int64_t ld, int64_t cap, int32_t* n_samples,
                            int32_t* sample_rates, int32_t* status, int32_t threads);
 
+/* The general ingest path of ONE file (replaces /root/reference/infer.py:217-220 soundfile.read + torchaudio resample, 234-235
+ * whole-clip peak normalisation, 237-244 + 19-28 split_audio for clips longer than chunk_samples, 114-115 per-chunk
+ * re-normalisation): rows out + r * ld receive the float32 work items, lens[r] their lengths.  Resampling = torchaudio's sinc /
+ * Hann algorithm restated (parity with torchaudio UNPINNED: library absent).  Status as wfl_host_load_wav, 5 = more than max_rows
+ * chunks (n_rows = the count needed, nothing written). */
+int32_t wfl_host_load_wav_chunks(const char* path, int32_t target_sr, int64_t chunk_samples, float* out, int64_t ld, int32_t max_rows,
+                                 int32_t* n_rows, int32_t* lens, int32_t* sample_rate);
+
 #ifdef __cplusplus
 }
 #endif

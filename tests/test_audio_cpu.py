@@ -78,3 +78,48 @@ def test_normalise_and_chunking():
     assert [len(c) for c in ch] == [480000, 480000, 80000]
     for c in ch:                                                 # every chunk re-normalised to peak 1 (infer.py:115)
         assert abs(float(np.abs(c).max()) - 1.0) < 1e-6
+
+
+def test_native_items_equal_python_path(tmp_path):
+    """wfl_host_load_wav_chunks (decode, resample, whole-clip normalise, 30 s chunks, per-chunk re-normalise) against
+    chunk_clip(load_clip(path)): bit-identical at 16 kHz, within float64 summation order after resampling."""
+    rng = np.random.RandomState(5)
+    sr = 16000
+    cases = {
+        "short.wav": (rng.randn(sr * 3) * 0.1, 16000),
+        "exact30.wav": (rng.randn(sr * 30) * 0.05, 16000),
+        "long.wav": (rng.randn(sr * 65) * 0.07, 16000),
+        "hi.wav": (rng.randn(44100 * 2) * 0.1, 44100),
+        "lo.wav": (rng.randn(8000 * 2) * 0.1, 8000),
+        "longhi.wav": (rng.randn(22050 * 40) * 0.1, 22050),
+    }
+    for name, (x, rate) in cases.items():
+        p = str(tmp_path / name)
+        A.write_wav(p, x, rate)
+        ref = A.chunk_clip(A.load_clip(p, sr), sr)
+        got = A.load_items(p, sr)
+        assert got is not None and [len(g) for g in got] == [len(r) for r in ref], name
+        for g, r in zip(got, ref):
+            assert g.dtype == np.float32
+            if rate == sr:
+                assert np.array_equal(g, r), name
+            else:
+                assert np.abs(g - r).max() <= 2e-7, name             # a float32 ulp at |x| <= 1
+    # stereo float file, and an encoding the native decoder refuses
+    st = np.stack([np.full(100, 0.25, np.float32), np.full(100, -0.75, np.float32)], axis=1)
+    p = str(tmp_path / "st.wav")
+    _raw_wav(p, 3, 2, 16000, 32, st.tobytes())
+    assert np.array_equal(A.load_items(p)[0], A.chunk_clip(A.load_clip(p))[0])
+    _raw_wav(p, 1, 3, 16000, 16, np.zeros(30, "<i2").tobytes())
+    assert A.load_items(p) is None
+    assert A.load_items(str(tmp_path / "missing.wav")) is None
+
+
+def test_native_lab_text_equals_save_lab(tmp_path):
+    from wfl_asr_amd import native_post as npost
+    from wfl_asr_amd import postprocess as pp
+    segs = [(0.009775376, 0.1915219, "d"), (0.29, 0.3, "SP"), (1.23456789, 2.0, "あ"), (2.0, 2.0000001, "d")]
+    p = str(tmp_path / "x.lab")
+    pp.save_lab(p, segs)
+    assert npost.format_lab_tuples(segs) == open(p, "rb").read()
+    assert npost.format_lab_tuples([]) == b""

@@ -50,11 +50,10 @@ def workdir(tmp_path_factory):
 
 def _manual(lab, path, lang_id, thr):
     """The reference's loop spelled out with single-row label() calls (infer.py:237-325)."""
-    audio = A.load_clip(path, 16000)
     lang_name = lab._lang_name(lang_id)
     out, clock = [], 0.0
-    chunks = A.chunk_clip(audio, 16000)
-    raw = A.split_audio(audio, 16000) if len(chunks) > 1 else [audio]
+    chunks = A.load_items(path, 16000)       # the product's ingest (native; held against the Python restatement in test_audio_cpu.py)
+    raw = chunks
     for c, r in zip(chunks, raw):
         x = torch.from_numpy(np.ascontiguousarray(c))[None].cuda()
         res = lab.model.label(x, None if lang_id is None else [lang_id], threshold=thr, average_languages=lang_id is None)

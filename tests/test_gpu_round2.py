@@ -176,3 +176,35 @@ def test_pipelined_loop_many_batches_equals_single_row_loop(tmp_path):
             assert segs == _manual(lab, path, lang_id, 0.3), (path, lang_id)
     lab.model.check(2, 480000, slot=0)
     lab.model.check(2, 480000, slot=1)
+
+
+@pytest.mark.parametrize("idx,B,L", [(2, 64, 160000), (3, 64, 480000)])
+def test_full_size_properties_cfg3_cfg4(idx, B, L):
+    """BASELINE configs[2] (WavLM-large + 2-layer BiLSTM H=512 + dilated stack, 64 x 10 s) and configs[3] per GPU (Whisper-small +
+    the full default head, 64 x 30 s = 512 / 8 GPUs) at FULL size: multi-tile persistent GEMMs, attention_big (head_dim 512 / 384),
+    four clip groups x 16 / 12 slice workgroups per direction in the recurrence.  No oracle run at this size (minutes of CPU):
+    the size-independent properties instead -- finite outputs, the decision rule frame by frame, bit-exact batch invariance
+    (a clip labelled alone equals the same clip inside the batch of 64), determinism, and a clean status word."""
+    cfg = synth.baseline_config(idx)
+    m, labels, _ = _build(cfg, 70, seed=70 + idx)
+    base = synth.make_batch(6000 + 100 * idx, 16, L, seed=70 + idx)
+    wav = np.stack([np.roll(base[i % 16], 1231 * (i // 16)) * (1.0 - 0.05 * (i // 16)) for i in range(B)]).astype(np.float32)
+    lang = (np.arange(B) % 2).astype(np.int64)
+    x = torch.from_numpy(wav).cuda()
+    full = m.label(x, lang, threshold=0.5, want_logits=True)
+    m.check(B, L)
+    assert int(full.status.item()) == 0
+    assert bool(torch.isfinite(full.logits).all()) and bool(torch.isfinite(full.offsets).all())
+    assert bool(((full.offsets >= 0) & (full.offsets <= 1)).all())
+    assert bool(((full.maxprob > 0) & (full.maxprob <= 1.0 + 1e-6)).all())
+    want = torch.where(full.maxprob < 0.5, torch.full_like(full.argmax, labels.index("O")), full.argmax)
+    assert torch.equal(full.ids, want)
+    assert torch.equal(full.argmax.long(), full.logits.argmax(-1))
+    assert float(full.logits.std()) > 1e-3                         # not a constant output
+    for i in (0, 17, 63):                                          # clip groups 0, 1 and 3 of the recurrence
+        one = m.label(x[i:i + 1], lang[i:i + 1], threshold=0.5, want_logits=True)
+        assert torch.equal(one.logits[0], full.logits[i]), i
+        assert torch.equal(one.offsets[0], full.offsets[i]) and torch.equal(one.ids[0], full.ids[i])
+    again = m.label(x, lang, threshold=0.5, want_logits=True)
+    assert torch.equal(again.logits, full.logits) and torch.equal(again.ids, full.ids)
+    m.check(B, L)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "wfl_host_format_lab": (_L, [_P, _P, _P, _I, _P, _I, _P, _L]),
     "wfl_host_load_wav": (_I, [C.c_char_p, _P, _L, _P, _P]),
     "wfl_host_load_wavs": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _I]),
+    "wfl_host_load_wav_chunks": (_I, [C.c_char_p, _I, _L, _P, _L, _I, _P, _P, _P]),
     "wfl_gemm_profile_enable": (_I, [_P, _I]),
     "wfl_gemm_profile_read": (_I, [_P, _I, _P, _P, _P, _P, _P, _I]),
 }

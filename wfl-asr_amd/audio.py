@@ -151,6 +151,32 @@ def load_wavs_into(paths, rows, cap: int, threads: int = 8):
     return ns[:n], srs[:n], st[:n]
 
 
+def load_items(path: str, sample_rate: int = 16000):
+    """The general ingest path of one file in native code (csrc/hostpost.hip: wfl_host_load_wav_chunks): decode, resample,
+    whole-clip peak normalisation, 30 s chunking with per-chunk re-normalisation -> list of float32 work items, exactly what
+    `chunk_clip(load_clip(path))` returns (bit-identical without resampling; resampled clips agree to ~1e-12 before the
+    float32 cast -- numpy's BLAS sums in another order).  Returns None when the native decoder does not take the file
+    (unsupported encoding, > 2 channels): the caller falls back to the Python path."""
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    chunk = int(MAX_SEGMENT_DURATION * sample_rate)
+    rows = 4
+    while True:
+        buf = np.empty((rows, chunk), np.float32)
+        n_rows, sr = C.c_int32(0), C.c_int32(0)
+        lens = np.zeros(rows, np.int32)
+        st = lib.wfl_host_load_wav_chunks(os.fsencode(path), int(sample_rate), chunk, buf.ctypes.data_as(C.c_void_p), chunk, rows,
+                                          C.byref(n_rows), lens.ctypes.data_as(C.c_void_p), C.byref(sr))
+        if st == 5:
+            rows = int(n_rows.value)
+            continue
+        if st != 0:
+            return None
+        return [buf[r, :lens[r]].copy() for r in range(n_rows.value)]
+
+
 def chunk_clip(audio: np.ndarray, sr: int = 16000):
     """The reference's two cases (infer.py:237-244): <= 30 s -> one item as is; longer -> non-overlapping 30 s chunks,
     each re-normalised (process_segments, infer.py:114-115).  Returns float32 arrays (infer.py:134, 251)."""

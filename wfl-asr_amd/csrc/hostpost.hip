@@ -200,9 +200,10 @@ bool parse_wav(const std::vector<unsigned char>& d, WavInfo& w) {
   return have_fmt && have_data;
 }
 
-// status: 0 ok; 1 not a WAV / unsupported encoding; 2 more than 2 channels; 3 longer than cap; 4 cannot open
-int load_one(const char* path, float* out, long cap, int32_t* n_out, int32_t* sr_out) {
-  *n_out = 0; *sr_out = 0;
+// Decode a WAV file to float64 mono samples (soundfile.read semantics, 2 channels averaged).
+// status: 0 ok; 1 not a WAV / unsupported encoding / NaN samples; 2 more than 2 channels; 4 cannot open
+int decode_mono(const char* path, std::vector<double>& mono, int32_t* sr_out) {
+  *sr_out = 0;
   FILE* f = fopen(path, "rb");
   if (!f) return 4;
   std::vector<unsigned char> d;
@@ -220,7 +221,6 @@ int load_one(const char* path, float* out, long cap, int32_t* n_out, int32_t* sr
   if (w.ch > 2) return 2;
   const size_t total = w.pcm_bytes / (size_t)bps;             // scalar samples
   const size_t frames = total / (size_t)w.ch;
-  if ((long)frames > cap) { *n_out = (int32_t)std::min<size_t>(frames, 0x7fffffff); return 3; }
   auto sample = [&](size_t i) -> double {
     const unsigned char* p = w.pcm + i * (size_t)bps;
     if (w.tag == 1) {
@@ -233,22 +233,74 @@ int load_one(const char* path, float* out, long cap, int32_t* n_out, int32_t* sr
     if (w.bits == 32) { float v; memcpy(&v, p, 4); return (double)v; }
     double v; memcpy(&v, p, 8); return v;
   };
-  // pass 1: peak of |mono|;  mono of 2 channels = (a + b) / 2, numpy's mean over a length-2 axis
+  mono.resize(frames);
+  for (size_t i = 0; i < frames; ++i) {
+    // mono of 2 channels = (a + b) / 2, numpy's mean over a length-2 axis
+    const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
+    if (x != x) return 1;                                      // numpy's max would propagate the NaN: leave it to the Python path
+    mono[i] = x;
+  }
+  return 0;
+}
+
+// x / (max|x| + 1e-8) in float64 (infer.py:234-235, :115), stored as float32 (infer.py:134, 251)
+void normalise_to_f32(const double* x, size_t n, float* out) {
   double peak = 0.0;
-  bool nan_seen = false;
-  for (size_t i = 0; i < frames; ++i) {
-    const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
-    const double a = std::fabs(x);
-    if (a != a) nan_seen = true;
-    if (a > peak) peak = a;
-  }
-  if (nan_seen) return 1;                                      // numpy's max would propagate the NaN: leave it to the Python path
+  for (size_t i = 0; i < n; ++i) { const double a = std::fabs(x[i]); if (a > peak) peak = a; }
   const double den = peak + 1e-8;
-  for (size_t i = 0; i < frames; ++i) {
-    const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
-    out[i] = (float)(x / den);
+  for (size_t i = 0; i < n; ++i) out[i] = (float)(x[i] / den);
+}
+
+// Band-limited sinc resampling, Hann window, lowpass_filter_width 6, rolloff 0.99: torchaudio.functional.resample's published
+// algorithm, the same arithmetic as wfl-asr_amd/audio.py:resample (parity with torchaudio itself is UNPINNED: the library is
+// absent here and the reference holds no resampled fixtures).  float64 throughout.
+void resample_f64(const std::vector<double>& x, int orig_freq, int new_freq, std::vector<double>& out) {
+  if (orig_freq == new_freq || x.empty()) { out = x; return; }
+  int a = orig_freq, b = new_freq;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int orig = orig_freq / a, nw = new_freq / a;
+  const double lpw = 6.0, rolloff = 0.99;
+  const double base = (double)std::min(orig, nw) * rolloff;
+  const int width = (int)std::ceil(lpw * orig / base);
+  const int klen = 2 * width + orig;
+  std::vector<double> kern((size_t)nw * klen);
+  const double scale = base / orig;
+  for (int i = 0; i < nw; ++i)
+    for (int j = 0; j < klen; ++j) {
+      double t = (-(double)i / nw + (double)(j - width) / orig) * base;
+      t = std::min(std::max(t, -lpw), lpw);
+      const double c = std::cos(t * M_PI / lpw / 2.0);
+      const double window = c * c;
+      t *= M_PI;
+      kern[(size_t)i * klen + j] = (t == 0.0 ? 1.0 : std::sin(t) / t) * window * scale;
+    }
+  const size_t length = x.size();
+  std::vector<double> xp(length + 2 * (size_t)width + orig, 0.0);
+  memcpy(xp.data() + width, x.data(), length * sizeof(double));
+  const size_t nfr = (xp.size() - klen) / orig + 1;
+  const size_t target = (size_t)std::ceil((double)nw * (double)length / orig);
+  out.assign(nfr * nw, 0.0);
+  for (size_t f = 0; f < nfr; ++f) {
+    const double* src = xp.data() + f * orig;
+    for (int i = 0; i < nw; ++i) {
+      const double* k = kern.data() + (size_t)i * klen;
+      double acc = 0.0;
+      for (int j = 0; j < klen; ++j) acc += src[j] * k[j];
+      out[f * nw + i] = acc;
+    }
   }
-  *n_out = (int32_t)frames;
+  if (out.size() > target) out.resize(target);
+}
+
+// status: 0 ok; 1 not a WAV / unsupported encoding; 2 more than 2 channels; 3 longer than cap; 4 cannot open
+int load_one(const char* path, float* out, long cap, int32_t* n_out, int32_t* sr_out) {
+  *n_out = 0;
+  std::vector<double> mono;
+  const int st = decode_mono(path, mono, sr_out);
+  if (st) return st;
+  if ((long)mono.size() > cap) { *n_out = (int32_t)std::min<size_t>(mono.size(), 0x7fffffff); return 3; }
+  normalise_to_f32(mono.data(), mono.size(), out);
+  *n_out = (int32_t)mono.size();
   return 0;
 }
 
@@ -279,6 +331,46 @@ int32_t wfl_host_load_wavs(const char* const* paths, int32_t n, float* out, int6
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; ++t) pool.emplace_back(work);
   for (auto& t : pool) t.join();
+  return 0;
+}
+
+// The general ingest path of one file (infer.py:217-220, 234-244, 19-28, 114-115): decode, resample to target_sr, peak-normalise
+// the whole clip, cut into non-overlapping chunks of chunk_samples when it is longer than that, re-normalise every chunk of a
+// cut clip, store rows as float32.  rows: out + r * ld; n_rows / lens report what was written.
+// status as wfl_host_load_wav, plus 5 = more than max_rows chunks (nothing written).
+int32_t wfl_host_load_wav_chunks(const char* path, int32_t target_sr, int64_t chunk_samples, float* out, int64_t ld, int32_t max_rows,
+                                 int32_t* n_rows, int32_t* lens, int32_t* sample_rate) {
+  if (!path || !out || !n_rows || !lens || !sample_rate || chunk_samples <= 0 || chunk_samples > ld || target_sr <= 0 || max_rows <= 0)
+    return -1;
+  *n_rows = 0;
+  std::vector<double> mono, rs;
+  const int st = decode_mono(path, mono, sample_rate);
+  if (st) return st;
+  const std::vector<double>* x = &mono;
+  if (*sample_rate != target_sr) { resample_f64(mono, *sample_rate, target_sr, rs); x = &rs; }
+  const size_t n = x->size();
+  // whole-clip peak normalisation (infer.py:234-235; an empty clip stays empty)
+  std::vector<double> norm(n);
+  {
+    double peak = 0.0;
+    for (size_t i = 0; i < n; ++i) { const double a = std::fabs((*x)[i]); if (a > peak) peak = a; }
+    const double den = peak + 1e-8;
+    for (size_t i = 0; i < n; ++i) norm[i] = (*x)[i] / den;
+  }
+  if (n <= (size_t)chunk_samples) {                        // <= 30 s: one item as is (infer.py:237, 251)
+    for (size_t i = 0; i < n; ++i) out[i] = (float)norm[i];
+    lens[0] = (int32_t)n;
+    *n_rows = 1;
+    return 0;
+  }
+  const size_t rows = (n + (size_t)chunk_samples - 1) / (size_t)chunk_samples;
+  if (rows > (size_t)max_rows) { *n_rows = (int32_t)std::min<size_t>(rows, 0x7fffffff); return 5; }
+  for (size_t r = 0; r < rows; ++r) {                      // split_audio (infer.py:19-28) + per-segment normalisation (infer.py:115)
+    const size_t lo = r * (size_t)chunk_samples, len = std::min((size_t)chunk_samples, n - lo);
+    normalise_to_f32(norm.data() + lo, len, out + r * (size_t)ld);
+    lens[r] = (int32_t)len;
+  }
+  *n_rows = (int32_t)rows;
   return 0;
 }
 

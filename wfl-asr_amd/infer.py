@@ -247,11 +247,13 @@ class Labeler:
         for fi, path in enumerate(audio_paths):
             if fi in decided_fast:
                 continue
-            audio = A.load_clip(path, self.sr)
-            if verbose and len(audio) / self.sr > MAX_SEGMENT_DURATION:
-                print(f"Audio is too long ({len(audio)/self.sr:.1f}s), splitting...")
-            chunks = A.chunk_clip(audio, self.sr)
-            lens = [len(c) for c in A.split_audio(audio, self.sr)] if len(chunks) > 1 else [len(audio)]
+            chunks = A.load_items(path, self.sr)            # native: decode, resample, normalise, 30 s chunks (csrc/hostpost.hip)
+            if chunks is None:                              # an encoding the native decoder does not take: the Python restatement
+                audio = A.load_clip(path, self.sr)
+                chunks = A.chunk_clip(audio, self.sr)
+            lens = [len(c) for c in chunks]
+            if verbose and len(chunks) > 1:
+                print(f"Audio is too long ({sum(lens)/self.sr:.1f}s), splitting...")
             for c, n in zip(chunks, lens):
                 items.append(c)
                 owner.append(fi)
@@ -317,10 +319,12 @@ def _labeler(config_path, checkpoint_path, device):
 
 
 def _write_lab(path, segments):
+    """save_lab (utils.py:76-81) with the text produced by the native formatter (wfl_host_format_lab: truncating int(t * 1e7))."""
     d = os.path.dirname(path)
     if d:
         os.makedirs(d, exist_ok=True)
-    pp.save_lab(path, segments)
+    with open(path, "wb") as f:
+        f.write(npost.format_lab_tuples(segments))
     print(f"Predictions saved to: {path}")
 
 

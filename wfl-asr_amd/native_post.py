@@ -103,6 +103,20 @@ def format_lab(s, e, ph, names) -> bytes:
     return buf.raw[:n]
 
 
+def format_lab_tuples(segments) -> bytes:
+    """[(start_s, end_s, phoneme)] -> the `.lab` text (UTF-8), through the native formatter."""
+    names, index = [], {}
+    ph = np.empty(len(segments), np.int32)
+    for i, (_, _, name) in enumerate(segments):
+        if name not in index:
+            index[name] = len(names)
+            names.append(name)
+        ph[i] = index[name]
+    s = np.array([a for a, _, _ in segments], np.float64)
+    e = np.array([b for _, b, _ in segments], np.float64)
+    return format_lab(s, e, ph, names) if len(segments) else b""
+
+
 def to_tuples(s, e, ph, names):
     """[(start_s, end_s, phoneme)] with Python floats, the reference's return type."""
     return [(float(a), float(b), names[int(p)]) for a, b, p in zip(s, e, ph)]
