@@ -313,6 +313,8 @@ def main():
 
     if rank == 0:
         audio_s = world * B * clip_seconds * args.steps
+        m = cfg["model"]
+        enc_name = m["whisper_model"] if m["encoder_type"] == "whisper" else m["wavlm_model"]
         roof = None
         if prof:
             acts = {0: 0, 1: 1, 2: 2, 3: 3}
@@ -322,9 +324,9 @@ def main():
                 act, glu, f32, res, kid = key & 3, bool(key & 4), bool(key & 8), bool(key & 16), (key >> 5) & 7
                 lnf, stats = (key >> 8) & 3, bool(key & 1024)
                 tf = lambda b: "true" if b else "false"
-                if kid in (1, 5, 6):                  # 6 = the tap-stationary conv mode
-                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
-                                                                           tf(kid == 6))
+                if kid in (1, 5, 6, 7):               # 6 = the tap-stationary conv mode, 7 = fp8 (e4m3) weights
+                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s%s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
+                                                                             tf(kid == 6), ", true" if kid == 7 else "")
                 if kid in (2, 3):
                     return "gemm256_kernel<%d, %s, %s, %d>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
                 return "gemm_bf16_kernel<%d, %s, %s>" % (acts[act], tf(glu), tf(f32))
@@ -362,12 +364,11 @@ def main():
                 "top_variant": {"kernel": kname(top["key"]), "avg_us": 1e3 * top["ms"] / top["launches"],
                                 "tflops": top["flops"] / top["ms"] / 1e9},
             }
-        m = cfg["model"]
-        enc_name = m["whisper_model"] if m["encoder_type"] == "whisper" else m["wavlm_model"]
         result = {
             "metric": "audio_seconds_labeled_per_sec_per_node", "value": audio_s / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 (fp8 e4m3 encoder weights)" if str(m.get("weight_dtype", "bf16")) == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": ("default config.yaml head: " if args.full_head else "BASELINE configs[%d]: " % args.config_index)
                        + "%s + %s%d Conformer blocks%s, %d x %g s clips per GPU" % (
                 enc_name, "%d-layer BiLSTM + " % m["bilstm_num_layer"] if m["enable_bilstm"] else "", m["num_conformer_layers"],

@@ -67,7 +67,9 @@ typedef struct wfl_arch {
   int32_t wavlm_num_buckets;
   int32_t wavlm_max_distance;
   int32_t wavlm_do_normalize;
-  int32_t reserved[10];
+  int32_t fp8_weights;               /* 1: the Whisper encoder layers' q|k|v, out_proj, fc1, fc2 weights are kept as OCP e4m3 with one
+                                        fp32 scale per output channel (BASELINE configs[4]); 0: bf16 */
+  int32_t reserved[9];
 } wfl_arch;
 
 const char* wfl_last_error(void);

@@ -338,32 +338,47 @@ def test_baseline_configs_3_and_4_vs_oracle(idx, B, L):
     assert bad == 0 and safe.float().mean() >= 0.5
 
 
-def test_baseline_config_5_width_vs_oracle():
-    """BASELINE configs[4] geometry (Whisper-large-v3: 128 mel bins, d = 1280, 20 heads, FFN 5120, linear head) at full width
-    with 4 of the 32 encoder layers, so that the CPU oracle finishes in seconds.  bf16 operands like every other config:
-    the fp8-weight variant BASELINE names for this config is not built yet (out of scope / next)."""
+@pytest.mark.parametrize("case", ["large_v3_4l", "base_6l"])
+def test_baseline_config_5_fp8_weights_vs_oracle(case):
+    """BASELINE configs[4]: Whisper-large-v3 encoder with fp8 weights (model.weight_dtype: fp8 -- q|k|v, out_proj, fc1, fc2 of every
+    layer as OCP e4m3 with one scale per output channel, converted to bf16 in registers in front of the bf16 MFMA), linear head.
+    "large_v3_4l" is the real geometry (128 mel bins, d = 1280, 20 heads, FFN 5120) with 4 of the 32 layers so that the CPU oracle
+    finishes in seconds; "base_6l" runs ALL layers of a smaller fp8 encoder (Whisper-base dims) so error growth through a whole
+    stack is covered too.  Two targets, as for bf16: the oracle on the fp8-rounded checkpoint (synth.round_weights_fp8: what is left
+    is activation rounding -- target A's tolerances) and the oracle on the checkpoint as given (an e4m3 weight carries 3 mantissa
+    bits, 32x coarser than bf16: reported, bounded loosely)."""
     cfg = synth.baseline_config(4)
-    cfg["model"]["whisper_model"] = "local/whisper-large-v3-4l"
-    cfg["model"]["encoder_arch"] = dict(d_model=1280, layers=4, heads=20, ffn=5120, n_mels=128, max_positions=1500)
+    assert cfg["model"]["weight_dtype"] == "fp8"
+    if case == "large_v3_4l":
+        cfg["model"]["whisper_model"] = "local/whisper-large-v3-4l"
+        cfg["model"]["encoder_arch"] = dict(d_model=1280, layers=4, heads=20, ffn=5120, n_mels=128, max_positions=1500)
+    else:
+        cfg["model"]["whisper_model"] = "local/whisper-base-fp8"
+        cfg["model"]["encoder_arch"] = dict(d_model=512, layers=6, heads=8, ffn=2048, n_mels=80, max_positions=1500)
     m, labels, sd_np = _build(cfg, 70, seed=45)
     B, L = 1, 160000
     wav = synth.make_batch(905, B, L, seed=45)
     lang = np.zeros(B, np.int64)
     out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True, want_hidden=True)
-    lg, of, hid = _oracle(cfg, labels, sd_np, wav, lang)
-    h_err = (out.hidden.cpu() - hid).abs()
-    _note("cfg5_hidden", max=h_err.max(), mean=h_err.mean())
-    assert h_err.max() <= 0.08 and h_err.mean() <= 0.012
-    ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
-    err = (out.logits.cpu() - lg).abs()
-    tau = TAU * float(lg.std()) / 6.5
-    safe = margin > tau
-    bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
-    _note("cfg5", logit_std=lg.std(), tau=tau, logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
-          safe_frac=safe.float().mean(), argmax_bad=bad, frames=int(arg_ref.numel()))
-    assert err.max() <= 0.40 and err.mean() <= 0.08
-    assert (out.offsets.cpu() - of).abs().max() <= 0.02
-    assert bad == 0 and safe.float().mean() >= 0.5
+    for target, sd_t in (("fp8_weights", synth.round_weights_fp8(sd_np)), ("fp32_weights", sd_np)):
+        lg, of, hid = _oracle(cfg, labels, sd_t, wav, lang)
+        h_err = (out.hidden.cpu() - hid).abs()
+        ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
+        err = (out.logits.cpu() - lg).abs()
+        tau = (TAU if target == "fp8_weights" else 4 * TAU) * float(lg.std()) / 6.5
+        safe = margin > tau
+        bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
+        _note(f"cfg5_fp8_{case}_{target}", hidden_max=h_err.max(), hidden_mean=h_err.mean(), logit_std=lg.std(), tau=tau,
+              logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
+              safe_frac=safe.float().mean(), argmax_bad=bad, argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()),
+              frames=int(arg_ref.numel()))
+        if target == "fp8_weights":
+            assert h_err.max() <= 0.08 and h_err.mean() <= 0.012
+            assert err.max() <= 0.40 and err.mean() <= 0.08
+            assert (out.offsets.cpu() - of).abs().max() <= 0.02
+        else:
+            assert h_err.mean() <= 0.08 and err.mean() <= 0.6
+        assert bad == 0
 
 
 def test_graph_replay_is_bit_identical():

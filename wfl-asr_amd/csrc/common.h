@@ -51,6 +51,9 @@ struct GemmArgs {
   const bf16_t* res_lo;     //   low half of the residual (ld = ldres), null: the residual is hi alone
   bf16_t* c_lo;             //   low half of the output (bf16 outputs only; ld = ldc, same row mapping as C), null: not kept
   int acc_f32;              // out_f32 only: C += result (the split-precision classifier adds its passes up in fp32)
+  // fp8 weights (BASELINE configs[4]): W is [N][K] OCP e4m3 bytes, one fp32 scale per output channel; the tile is converted to
+  // bf16 in registers (exact) in front of the bf16 MFMA, the scale multiplies the accumulator in the epilogue (gemm_stream.hip)
+  const float* w8_scale;    //   [N] per-output-channel scale, non-null <=> W holds e4m3 bytes
   float alpha;              // out = res + alpha * act(v)
   const bf16_t* pos;        // [T][ldpos] added after the activation (positional table) or null
   long ldpos;

@@ -367,11 +367,11 @@ int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (tile_pref() == 256) {
     int r = wfl_launch_gemm_stream(a, s);
     if (r != 1) return r;
-    if (a.ln_s) return -1;                          // only the streaming kernel folds a LayerNorm
+    if (a.ln_s || a.w8_scale) return -1;            // only the streaming kernel folds a LayerNorm / reads e4m3 weights
     r = wfl_launch_gemm256(a, s);
     if (r != 1) return r;
   }
-  if (a.ln_s) return -1;
+  if (a.ln_s || a.w8_scale) return -1;
   if (a.glu) {
     if (a.out_f32 || a.act != WFL_ACT_NONE) return -1;
     return launch_t<WFL_ACT_NONE, true, false>(a, s);

@@ -62,15 +62,20 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 //   frame operand of a whole chunk -- the tile's 192 rows plus the taps - 1 rows of overlap, 32 channels -- is staged ONCE and
 //   re-read at a one-row offset per tap, so a K step moves 16 KiB (the weight tile) instead of 28: the k = 31 Conformer conv
 //   (a quarter of the model's FLOPs) leaves the L2 -> LDS bound and becomes MFMA-bound.
-template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV>
+// W8: the weight operand is OCP e4m3 (one byte per element, per-output-channel fp32 scale p.w8_scale): the weight tile of a K
+//   step is 8 KiB instead of 16 (one LDS-DMA piece per wave instead of two: 20 KiB per step instead of 28 -- the K loop is bound
+//   by exactly these bytes), fragments are read as 8 bytes and converted to bf16 in registers (v_cvt_pk_f32_fp8 +
+//   v_cvt_pk_bf16_f32, exact), the MFMA stays bf16 x bf16, the scale multiplies the accumulator in the epilogue.
+template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   static_assert(!CONV || (MT == 6 && !RES && LNF == 0 && !STATS), "conv mode: 192-row tiles, plain epilogue");
+  static_assert(!W8 || (!CONV && MT == 6), "fp8 weights: plain 192-row mode");
   constexpr int BMV = MT * 32;                    // frame rows per tile
 #ifdef WFL_LAB_STB32
   constexpr int STB = 512 * SBK * 2;
   constexpr int WOFF = 256 * SBK * 2;
 #else
-  constexpr int STB = CONV ? 256 * SBK * 2 : (BMV + 256) * SBK * 2;      // stage bytes: frame tile then weight tile
+  constexpr int STB = CONV ? 256 * SBK * 2 : BMV * SBK * 2 + 256 * SBK * (W8 ? 1 : 2);   // stage bytes: frame tile then weight tile
   constexpr int WOFF = CONV ? 0 : BMV * SBK * 2;
 #endif
   constexpr int AEXT = 224 * SBK * 2;             // CONV: extended frame tile (BMV + up to 32 taps - 1 rows), two of them
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   const int ntaps = CONV ? p.K / p.cin : 1;
   const bf16_t* a_src[2];
   const bf16_t* w_src[2];
+  const char* w8_src = nullptr;                     // W8: this lane's 16 source bytes of the wave's ONE weight piece (32 rows x 32 bytes)
   int pv = blockIdx.x, pkt = 0, issued = 0;
   int ptap_k = 0;                                   // position inside the current tap (conv GEMMs), elements
   long pbase = 0;                                   // tap * tap_stride
@@ -124,6 +130,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       am = am < am_max ? am : am_max;
       a_src[i] = p.A + (long)am * p.lda + ((lane & 3) ^ (CONV ? xswz(xrow) : sswz(xrow))) * 8;
       w_src[i] = p.W + (long)(n0 + wrow) * p.K + ((lane & 3) ^ sswz(wrow)) * 8;
+    }
+    if (W8) {
+      // fp8 weight tile in LDS: 256 rows x 32 bytes; 8 rows = one 256-byte bank row = 32 slots of 8 bytes, slot (r & 7) * 4 + q for
+      // the q-th 8 k's of row r, XORed with ((r >> 3) & 1) << 1 | ((r >> 4) & 1) << 4 so that the 32 lanes of a ds_read_b64 group
+      // (rows 8 j + i, i, j < 4) hit 32 different slots.  The DMA writes lane l's 16 bytes to 16-byte unit l & 15 of bank row
+      // Gr = 4 wid + (l >> 4); it therefore FETCHES the logical unit (l & 15) ^ (Gr & 1 | (Gr >> 1 & 1) << 3).
+      const int Gr = wid * 4 + (lane >> 4);
+      const int ul = (lane & 15) ^ ((Gr & 1) | (((Gr >> 1) & 1) << 3));
+      w8_src = (const char*)p.W + (long)(n0 + 8 * Gr + (ul >> 1)) * p.K + (ul & 1) * 16;
     }
   };
   set_src(pv);
@@ -146,8 +161,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     char* base = smem + (issued & (SNST - 1)) * STB;
     sglds(a_src[0] + koff, base + xg0 * 1024);
     if (two_x) sglds(a_src[1] + koff, base + xg0 * 1024 + 1024);
+    if (W8) {
+      sglds((const bf16_t*)(w8_src + pkt * SBK), base + WOFF + wid * 1024);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) sglds(w_src[i] + pkt * SBK, base + WOFF + wid * 2048 + i * 1024);
+      for (int i = 0; i < 2; ++i) sglds(w_src[i] + pkt * SBK, base + WOFF + wid * 2048 + i * 1024);
+    }
     ++issued;
     ++pkt;
     ptap_k += SBK;
@@ -175,13 +194,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
       return;
     }
+    constexpr int L2X = W8 ? 3 : 4, L1X = W8 ? 2 : 3;     // DMA pieces per wave and stage (two / one frame pieces + weight pieces)
     if (two_x) {
-      if (younger >= 2) { if (with_stores) wait_vm<8 + NSTORE>(); else wait_vm<8>(); }
-      else if (younger == 1) { if (with_stores) wait_vm<4 + NSTORE>(); else wait_vm<4>(); }
+      if (younger >= 2) { if (with_stores) wait_vm<2 * L2X + NSTORE>(); else wait_vm<2 * L2X>(); }
+      else if (younger == 1) { if (with_stores) wait_vm<L2X + NSTORE>(); else wait_vm<L2X>(); }
       else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
     } else {
-      if (younger >= 2) { if (with_stores) wait_vm<6 + NSTORE>(); else wait_vm<6>(); }
-      else if (younger == 1) { if (with_stores) wait_vm<3 + NSTORE>(); else wait_vm<3>(); }
+      if (younger >= 2) { if (with_stores) wait_vm<2 * L1X + NSTORE>(); else wait_vm<2 * L1X>(); }
+      else if (younger == 1) { if (with_stores) wait_vm<L1X + NSTORE>(); else wait_vm<L1X>(); }
       else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
     }
   };
@@ -197,7 +217,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #else
     const int r = wn + 32 * (v >> 1) + 8 * (c >> 2) + 4 * (v & 1) + (c & 3);
 #endif
-    w_off[v] = WOFF + r * 64 + ((g ^ sswz(r)) << 4);
+    w_off[v] = W8 ? WOFF + (r >> 3) * 256 + ((((r & 7) * 4 + g) ^ (((r >> 3) & 1) << 1) ^ (((r >> 4) & 1) << 4)) << 3)
+                  : WOFF + r * 64 + ((g ^ sswz(r)) << 4);
   }
   const int x_off = wm * 64 + c * 64 + ((g ^ sswz(c)) << 4);      // + u * 1024 (16 rows; sswz(16u + c) == sswz(c))
 
@@ -212,13 +233,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   // ---- epilogue of tile (m0, n0): registers -> HBM
   auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
     const int nb = n0 + wn + 8 * g;                 // first channel of this lane's first run; second run at +32
-    f32x4 bj[4], sj[4];
+    f32x4 bj[4], sj[4], cj[W8 ? 4 : 1];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         bj[2 * h + q] = p.bias ? *(const f32x4*)(p.bias + nb + 32 * h + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (LNF) sj[2 * h + q] = *(const f32x4*)(p.ln_s + nb + 32 * h + 4 * q);
+        if (W8) cj[2 * h + q] = *(const f32x4*)(p.w8_scale + nb + 32 * h + 4 * q);
       }
     const float invP = 1.0f / (float)p.P;
     int orow[MT];                                   // output row index, or -1 for rows that are not stored
@@ -294,6 +316,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[u][2 * h + q][e];
+            if (W8) v *= cj[2 * h + q][e];
             if (LNF) v = (v - mu[u] * sj[2 * h + q][e]) * rs[u];
             v = apply_act<ACT>(v + bj[2 * h + q][e]);
             if (RES) v = (bf2f(rr[u % RING][h][4 * q + e]) + lo_scale * bf2f(rl[u % RING][h][4 * q + e])) + p.alpha * v;
@@ -371,8 +394,19 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   int ctap = 0, ccg = 0;                              // CONV: tap of the step being computed; chunks finished (buffer parity)
   auto read_frags = [&]() __attribute__((always_inline)) {
     const char* sb = smem + (s & (SNST - 1)) * STB;
+    if (W8) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) fw[v] = *(const bf16x8*)(sb + w_off[v]);
+      for (int v = 0; v < 4; ++v) {
+        const uint2 raw = *(const uint2*)(sb + w_off[v]);
+        typedef __attribute__((ext_vector_type(2))) float f32x2_;
+        const f32x2_ a = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, true);
+        const f32x2_ c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, false), d2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, true);
+        fw[v] = (bf16x8){(bf16_t)a[0], (bf16_t)a[1], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)c2[0], (bf16_t)c2[1], (bf16_t)d2[0], (bf16_t)d2[1]};
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) fw[v] = *(const bf16x8*)(sb + w_off[v]);
+    }
     if (CONV) {
       const char* ab = smem + AOFF + (ccg & 1) * AEXT;
       const int r0 = wm + c + ctap;                  // row of the extended tile; + 16u never changes the swizzle
@@ -455,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // nothing but operand DMA is in the queue, so the waits are constants.  One copy per wave group (no per-step branches).
     auto steps_steady = [&](auto grp_c) __attribute__((always_inline)) {
       constexpr bool GRP1 = decltype(grp_c)::value;
-      constexpr int NL = CONV ? 2 : ((MT == 8 || !GRP1) ? 4 : 3);
+      constexpr int NL = CONV ? 2 : ((MT == 8 || !GRP1) ? (W8 ? 3 : 4) : (W8 ? 2 : 3));
       for (int kt = 2; kt <= nk - 5; ++kt) {
 #ifndef WFL_ABL_NOLDS          // diagnostic builds (tools/gemm_lab.py): no fragment reads / no operand DMA in the steady loop
         read_frags();
@@ -492,21 +526,21 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #undef SSB
 }
 
-template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV = false>
+template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV = false, bool W8 = false>
 static int launch_stream(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
 #ifdef WFL_LAB_STB32
   constexpr int lds = SNST * 512 * SBK * 2 + 8 * (MT * 16) * 2 * 4 + 64;
 #else
-  constexpr int lds = (CONV ? SNST * 256 * SBK * 2 + 2 * 224 * SBK * 2 : SNST * (BMV + 256) * SBK * 2) + 8 * (MT * 16) * 2 * 4 + 64;
+  constexpr int lds = (CONV ? SNST * 256 * SBK * 2 + 2 * 224 * SBK * 2 : SNST * (BMV * SBK * 2 + 256 * SBK * (W8 ? 1 : 2))) + 8 * (MT * 16) * 2 * 4 + 64;
 #endif
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
-  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV>;
+  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV, W8>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
-  g_wfl_gemm_kernel_id = CONV ? 6 : (MT == 6 ? 1 : 5);
+  g_wfl_gemm_kernel_id = CONV ? 6 : (W8 ? 7 : (MT == 6 ? 1 : 5));
   hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -545,7 +579,8 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   return false;
 #endif
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
-  if (a.c_lo && !a.res) return false;                 // only the residual epilogue here keeps a low half (gemm256 / gemm do it for any)
+  if (a.c_lo && !a.res) return false;
+  if (a.w8_scale && (a.cin < a.K || a.K % 64)) return false;                 // only the residual epilogue here keeps a low half (gemm256 / gemm do it for any)
   if (a.N % 256 || a.K % SBK || a.cin % SBK || a.K / SBK < 8 || a.n_valid % 8) return false;
   // (no lower bound on M: a LayerNorm folded through the producer's statistics must not depend on the batch size -- a clip
   // labelled alone has to equal the same clip inside a batch bit for bit)
@@ -569,6 +604,23 @@ int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs g = a;
   g.trash = trash[dev];
+  if (g.w8_scale) {
+    // fp8-weight launches: the Whisper encoder's LayerNorm-folded projections (statistics from the producer) and its residual
+    // GEMMs (statistics emitted), i.e. everything between the stem and the final LayerNorm
+    if (g.ln_s && g.stats_in) {
+      if (g.act == WFL_ACT_NONE) return launch_stream<WFL_ACT_NONE, 6, false, 2, false, false, true>(g, s);
+      if (g.act == WFL_ACT_GELU) return launch_stream<WFL_ACT_GELU, 6, false, 2, false, false, true>(g, s);
+      return -1;
+    }
+    if (g.res && !g.ln_s && g.act == WFL_ACT_NONE)
+      return g.stats_out ? launch_stream<WFL_ACT_NONE, 6, true, 0, true, false, true>(g, s)
+                         : launch_stream<WFL_ACT_NONE, 6, true, 0, false, false, true>(g, s);
+    if (!g.res && !g.ln_s) {
+      if (g.act == WFL_ACT_NONE) return launch_stream<WFL_ACT_NONE, 6, false, 0, false, false, true>(g, s);
+      if (g.act == WFL_ACT_GELU) return launch_stream<WFL_ACT_GELU, 6, false, 0, false, false, true>(g, s);
+    }
+    return -1;                                         // no other kernel reads e4m3 weights
+  }
   if (g.ln_s) {
     if (g.stats_in) {
       switch (g.act) {

@@ -115,6 +115,7 @@ struct Lin {
   float* bias = nullptr; // [N] padded (may be null)
   int N = 0, K = 0, n_valid = 0;
   float* ln_s = nullptr; // set on a LayerNorm-folded operand: s[n] = sum_k W'[n][k] (gemm_stream.hip), bias = b + W beta
+  float* w8 = nullptr;   // set on an fp8 operand: W holds OCP e4m3 bytes [N][K], w8[n] = the row's scale (GemmArgs::w8_scale)
 };
 struct LNp { float* g = nullptr; float* b = nullptr; };
 
@@ -194,6 +195,8 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (a.n_conformer > 0 && (a.conformer_heads <= 0 || a.d_model % a.conformer_heads)) return fail(-1, "bad conformer_heads");
   if (a.n_conformer > 0 && a.conformer_kernel % 2 == 0) return fail(-1, "even conformer_kernel_size is not supported");
   if (a.enable_dilated && a.dilated_kernel % 2 == 0) return fail(-1, "even dilated_conv_kernel is not supported");
+  if (a.fp8_weights && (a.encoder_type != WFL_ENC_WHISPER || a.d_model % 256 || a.enc_ffn % 256))
+    return fail(-1, "fp8_weights: Whisper encoders with d_model and ffn multiples of 256 only");
   wfl_model* m = new wfl_model();
   m->a = a;
   int pad = 1;
@@ -292,6 +295,62 @@ struct Packer {
     if (bias) for (int n = 0; n < n_valid; ++n) b[n] = (*bias)[n];
     L.bias = upload(b);
     return L;
+  }
+
+  // OCP e4m3 (fn) encode, round to nearest even, saturating at 448: nearest entry of the 127 non-negative code points
+  static uint8_t e4m3_encode(float x) {
+    static float tab[127];
+    static bool init = false;
+    if (!init) {
+      for (int b = 0; b < 127; ++b) {
+        const int e = b >> 3, mnt = b & 7;
+        tab[b] = e == 0 ? (float)mnt / 8.0f * 0.015625f : (1.0f + (float)mnt / 8.0f) * std::ldexp(1.0f, e - 7);
+      }
+      init = true;
+    }
+    const uint8_t sign = std::signbit(x) ? 0x80 : 0;
+    const float a = std::fabs(x);
+    if (!(a == a)) return 0x7F;
+    if (a >= 448.0f) return sign | 126;
+    int lo = 0, hi = 126;                       // tab[lo] <= a < tab[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tab[mid] <= a) lo = mid; else hi = mid; }
+    const float dl = a - tab[lo], dh = tab[hi] - a;
+    const int pick = dl < dh ? lo : (dh < dl ? hi : ((lo & 1) ? hi : lo));
+    return sign | (uint8_t)pick;
+  }
+  static float e4m3_decode(uint8_t b) {
+    const int e = (b >> 3) & 15, mnt = b & 7;
+    const float v = e == 0 ? (float)mnt / 8.0f * 0.015625f : (1.0f + (float)mnt / 8.0f) * std::ldexp(1.0f, e - 7);
+    return (b & 0x80) ? -v : v;
+  }
+
+  // rows[n][k] fp32 -> e4m3 bytes [N][K] (padded) + per-row fp32 scale (row max -> 448) + fp32 bias [N]
+  Lin pack8(const std::vector<float>& rows, int n_valid, int k_valid, const std::vector<float>* bias) {
+    Lin L;
+    L.n_valid = n_valid;
+    L.N = (int)round_up(n_valid, 256);
+    L.K = (int)round_up(k_valid, 64);
+    std::vector<uint8_t> w((size_t)L.N * L.K, 0);
+    std::vector<float> sc((size_t)L.N, 1.0f);
+    for (int n = 0; n < n_valid; ++n) {
+      float mx = 0.f;
+      for (int k = 0; k < k_valid; ++k) mx = std::max(mx, std::fabs(rows[(size_t)n * k_valid + k]));
+      const float scale = mx > 0.f ? mx / 448.0f : 1.0f;
+      sc[n] = scale;
+      for (int k = 0; k < k_valid; ++k) w[(size_t)n * L.K + k] = e4m3_encode(rows[(size_t)n * k_valid + k] / scale);
+    }
+    L.W = (bf16_t*)upload(w);
+    L.w8 = upload(sc);
+    std::vector<float> b((size_t)L.N, 0.f);
+    if (bias) for (int n = 0; n < n_valid; ++n) b[n] = (*bias)[n];
+    L.bias = upload(b);
+    return L;
+  }
+  Lin linear8(const std::string& p, int out_f, int in_f) {
+    const HostTensor* w = get(p + ".weight", {out_f, in_f});
+    const HostTensor* b = get(p + ".bias", {out_f});
+    if (!w || !b) return Lin();
+    return pack8(w->data, out_f, in_f, &b->data);
   }
 
   // LayerNorm(gamma, beta) folded into the Linear that consumes it (gemm_stream.hip): W' = gamma o W rounded to bf16,
@@ -456,13 +515,25 @@ static int finalize_whisper(wfl_model* m, Packer& P) {
         rows[(size_t)2 * d * d + j] = wv->data[j];
       }
       for (int j = 0; j < d; ++j) { bias[j] = bq->data[j] * qs; bias[2 * d + j] = bv->data[j]; }
-      L.qkv = P.pack(rows, 3 * d, d, &bias);
-      L.qkv_ln = P.pack_ln(rows, 3 * d, d, &bias, p + "self_attn_layer_norm");
+      if (a.fp8_weights) {
+        L.qkv = P.pack8(rows, 3 * d, d, &bias);
+      } else {
+        L.qkv = P.pack(rows, 3 * d, d, &bias);
+        L.qkv_ln = P.pack_ln(rows, 3 * d, d, &bias, p + "self_attn_layer_norm");
+      }
     }
-    L.out = P.linear(p + "self_attn.out_proj", d, d);
-    L.fc1 = P.linear(p + "fc1", a.enc_ffn, d);
-    L.fc1_ln = P.linear_ln(p + "fc1", a.enc_ffn, d, p + "final_layer_norm");
-    L.fc2 = P.linear(p + "fc2", d, a.enc_ffn);
+    if (a.fp8_weights) {
+      // fp8 weights (BASELINE configs[4]): the four big operands of every layer as e4m3 + per-channel scale; no LayerNorm folding
+      // (its gamma would have to go into the quantised tensor), the LayerNorm kernel feeds the plain fp8 GEMM
+      L.out = P.linear8(p + "self_attn.out_proj", d, d);
+      L.fc1 = P.linear8(p + "fc1", a.enc_ffn, d);
+      L.fc2 = P.linear8(p + "fc2", d, a.enc_ffn);
+    } else {
+      L.out = P.linear(p + "self_attn.out_proj", d, d);
+      L.fc1 = P.linear(p + "fc1", a.enc_ffn, d);
+      L.fc1_ln = P.linear_ln(p + "fc1", a.enc_ffn, d, p + "final_layer_norm");
+      L.fc2 = P.linear(p + "fc2", d, a.enc_ffn);
+    }
   }
   m->enc_ln = P.ln("encoder.layer_norm", d);
   return 0;
@@ -901,6 +972,7 @@ struct Runner {
     if (rc) return;
     GemmArgs g{};
     g.ln_s = W.ln_s; g.ln_eps = 1e-5f;
+    g.w8_scale = W.w8;
     if (W.ln_s && stats_in_next) { g.stats_in = (const float*)(ws + p.stats); g.stats_nsl = stats_nsl; g.stats_lead = p.lead; }
     stats_in_next = false;
     g.A = A; g.lda = lda;
@@ -921,7 +993,7 @@ struct Runner {
     next_flops = -1.0;
     if (C == stats_for) stats_for = nullptr;                       // the rows they describe are being overwritten
     if (res && !out_f32 && !glu && act == WFL_ACT_NONE && ldc == p.d && W.n_valid == p.d && c_lead == p.lead && c_pitch == p.P &&
-        P == p.P && ln_fold_mode() == 1) {
+        P == p.P && ln_fold_mode() == 1 && !W.w8) {
       g.stats_out = (float*)(ws + p.stats);
       if (wfl_gemm_stream_takes(g)) { stats_for = C; stats_nsl = W.N / 256; }
       else g.stats_out = nullptr;

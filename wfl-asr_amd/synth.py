@@ -216,6 +216,35 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
     return np.where(np.isfinite(a), r, a).astype(np.float32)
 
 
+_E4M3_POS = np.array([(m / 8.0) * 2.0 ** -6 if e == 0 else (1.0 + m / 8.0) * 2.0 ** (e - 7) for e in range(16) for m in range(8)][:127])
+
+
+def fp8_round_rows(w: np.ndarray) -> np.ndarray:
+    """[N, K] float32 -> the values an OCP e4m3 copy with one scale per row (row max -> 448) represents, as float32:
+    what csrc/model.hip's pack8 stores (round to nearest, ties to even code)."""
+    w = np.asarray(w, np.float32)
+    mx = np.abs(w).max(axis=1, keepdims=True)
+    scale = np.where(mx > 0, mx / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    a = (np.abs(w) / scale).astype(np.float32)
+    hi = np.clip(np.searchsorted(_E4M3_POS, a, side="right"), 1, 126)
+    lo = hi - 1
+    dl, dh = a - _E4M3_POS[lo], _E4M3_POS[hi] - a
+    pick = np.where(dl < dh, lo, np.where(dh < dl, hi, np.where(lo % 2 == 1, hi, lo)))
+    pick = np.where(a >= 448.0, 126, pick)
+    return (np.sign(w) * _E4M3_POS[pick].astype(np.float32) * scale).astype(np.float32)
+
+
+def round_weights_fp8(sd_np):
+    """The "fp8 checkpoint" of a Whisper state dict: q / k / v / out_proj / fc1 / fc2 weights of every encoder layer replaced by
+    their e4m3 + per-output-channel-scale values (model.weight_dtype: fp8), everything else as given."""
+    out = OrderedDict()
+    for k, v in sd_np.items():
+        hit = k.startswith("encoder.layers.") and k.endswith(".weight") and any(
+            t in k for t in ("q_proj", "k_proj", "v_proj", "out_proj", ".fc1.", ".fc2."))
+        out[k] = fp8_round_rows(v) if hit else v
+    return out
+
+
 def round_weights_bf16(sd_np):
     """The "bf16 checkpoint" of a state dict: every float tensor with two or more dimensions (Linear / Conv / embedding
     weights -- what the MI355X path keeps in bf16) rounded to bfloat16 and stored back as float32; biases, norm parameters
@@ -314,7 +343,7 @@ def baseline_config(i: int) -> dict:
         return base_config("wavlm", wavlm_model="microsoft/wavlm-large", num_conformer_layers=0)
     if i == 3:   # cfg4: Whisper-small + full head
         return base_config("whisper", whisper_model="openai/whisper-small")
-    if i == 4:   # cfg5: Whisper-large-v3 encoder
+    if i == 4:   # cfg5: Whisper-large-v3 encoder, fp8 weights (model.weight_dtype is this build's key: e4m3 + per-channel scale)
         return base_config("whisper", whisper_model="openai/whisper-large-v3", enable_bilstm=False,
-                           num_conformer_layers=0, enable_dilated_conv=False)
+                           num_conformer_layers=0, enable_dilated_conv=False, weight_dtype="fp8")
     raise IndexError(i)

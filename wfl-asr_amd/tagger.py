@@ -75,6 +75,7 @@ class BIOPhonemeTagger:
         a.d_model, a.enc_layers, a.enc_heads, a.enc_ffn = self.arch.d_model, self.arch.layers, self.arch.heads, self.arch.ffn
         if isinstance(self.arch, WhisperArch):
             a.n_mels, a.max_positions = self.arch.n_mels, self.arch.max_positions
+            a.fp8_weights = int(str(config["model"].get("weight_dtype", "bf16")).lower() in ("fp8", "e4m3", "float8_e4m3fn"))
             if (self.arch.n_fft, self.arch.hop) != (400, 160):
                 raise ValueError("the log-mel kernel is built for n_fft=400 / hop=160 (every Whisper checkpoint)")
         else:
