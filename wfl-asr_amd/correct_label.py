@@ -1,0 +1,179 @@
+"""Acoustic boundary snapping of `.lab` files: the step the reference's notebook runs right after inference
+(/root/reference/correct_label.py).
+
+  detect_boundaries       correct_label.py:15-38   spectral flux of a 512-point STFT + mean |delta| of 13 MFCCs, summed half and
+                                                   half, peak picking (height 0.1, distance 5 frames), peaks shifted one frame back
+  correct_lab_boundaries  correct_label.py:40-87   every start / end of a `.lab` line snaps to the nearest unused detected boundary
+                                                   within 30 ms (greedy, in file order, a boundary is used once)
+  write_lab / process_file  correct_label.py:139-177 (truncating int(t * 1e7), like save_lab)
+
+The reference computes the features with librosa 0.11 (`stft`, `feature.mfcc`, `feature.delta`); librosa is not available in this
+image and the reference holds no fixtures for this step, so the feature arithmetic is restated from librosa's documented
+definitions with numpy / scipy and its parity is UNPINNED (only its own properties are tested).  The snapping logic is exact
+Python and is pinned by a worked example.  Host-side: at 30 s per file the detector costs a few milliseconds; it is not on the
+GPU path.  Input audio must already be 16 kHz (librosa.load would resample with soxr, which is not restated).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import audio as A
+
+snap_threshold_sec = 0.03
+
+
+def _hann_periodic(n: int) -> np.ndarray:
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def _stft_mag(y: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
+    """|librosa.stft(y, n_fft, hop)|: periodic Hann of length n_fft, center=True with zero padding (librosa >= 0.10),
+    frames = 1 + len(y) // hop.  -> [1 + n_fft // 2, frames] float32."""
+    y = np.asarray(y, dtype=np.float32)
+    yp = np.pad(y, (n_fft // 2, n_fft // 2))
+    n_frames = 1 + (len(yp) - n_fft) // hop
+    frames = np.lib.stride_tricks.sliding_window_view(yp, n_fft)[::hop][:n_frames]
+    spec = np.fft.rfft(frames * _hann_periodic(n_fft).astype(np.float32), axis=1)
+    return np.abs(spec).T.astype(np.float32)
+
+
+def _mel_slaney(sr: int, n_fft: int, n_mels: int) -> np.ndarray:
+    """librosa.filters.mel(sr=sr, n_fft=n_fft, n_mels=n_mels): Slaney mel scale, Slaney area normalisation.  -> [n_mels, 1 + n_fft // 2]"""
+    def hz2mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+    def mel2hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+    fftfreqs = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel2hz(np.linspace(hz2mel(0.0), hz2mel(sr / 2.0), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0.0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def _mfcc(y: np.ndarray, sr: int, n_mfcc: int, hop: int) -> np.ndarray:
+    """librosa.feature.mfcc(y=y, sr=sr, n_mfcc=n_mfcc, hop_length=hop): power mel spectrogram (n_fft 2048, 128 mels) -> dB with
+    top_db 80 -> DCT-II, orthonormal, first n_mfcc rows."""
+    from scipy.fft import dct
+    power = _stft_mag(y, 2048, hop).astype(np.float32) ** 2
+    mel = _mel_slaney(sr, 2048, 128) @ power
+    log_spec = 10.0 * np.log10(np.maximum(1e-10, mel))
+    log_spec = np.maximum(log_spec, log_spec.max() - 80.0)
+    return dct(log_spec, axis=0, type=2, norm="ortho")[:n_mfcc]
+
+
+def detect_boundaries(y, sr, frame_length=512, hop_length=160, flux_threshold=0.1, delta_window=5):
+    """-> (boundary times [s], flux, mfcc-delta magnitude, frame times), as correct_label.py:15-38."""
+    from scipy.signal import find_peaks, savgol_filter
+    S = _stft_mag(y, frame_length, hop_length)
+    flux = np.sqrt(np.sum(np.diff(S, axis=1) ** 2, axis=0))
+    flux = np.pad(flux, (1,), mode="constant")
+    flux = flux / np.max(flux)
+    mfcc = _mfcc(y, sr, 13, hop_length)
+    delta = savgol_filter(mfcc, 9, deriv=1, axis=-1, polyorder=1, mode="interp")     # librosa.feature.delta defaults
+    delta_mag = np.mean(np.abs(delta), axis=0)
+    delta_mag = delta_mag / np.max(delta_mag)
+    n = min(len(flux), len(delta_mag))
+    flux, delta_mag = flux[:n], delta_mag[:n]
+    combined = 0.5 * flux + 0.5 * delta_mag
+    peaks, _ = find_peaks(combined, height=flux_threshold, distance=delta_window)
+    shifted = np.clip(peaks - 1, 0, len(combined) - 1)
+    times = shifted * hop_length / float(sr)
+    flux_times = np.arange(len(flux)) * hop_length / float(sr)
+    return times.tolist(), flux, delta_mag, flux_times
+
+
+def snap_segments(segments, predicted_boundaries, snap_threshold=snap_threshold_sec):
+    """The loop of correct_label.py:52-85 on [(start_s, end_s, label)]: start, then end, of every line takes the nearest boundary
+    not used before, if it lies within the threshold."""
+    used = set()
+    out = []
+    for start_sec, end_sec, label in segments:
+        for which in (0, 1):
+            t0 = start_sec if which == 0 else end_sec
+            closest, best = None, snap_threshold + 1
+            for t in predicted_boundaries:
+                if t in used:
+                    continue
+                dist = abs(t - t0)
+                if dist < best:
+                    best, closest = dist, t
+            if closest is not None and best <= snap_threshold:
+                used.add(closest)
+                if which == 0:
+                    start_sec = closest
+                else:
+                    end_sec = closest
+        out.append((start_sec, end_sec, label))
+    return out
+
+
+def read_lab(lab_path):
+    segs = []
+    with open(lab_path, "r") as f:
+        for line in f:
+            parts = line.strip().split()
+            if len(parts) == 3:
+                segs.append((float(parts[0]) / 1e7, float(parts[1]) / 1e7, parts[2]))
+    return segs
+
+
+def correct_lab_boundaries(wav_path, predicted_boundaries, snap_threshold=snap_threshold_sec):
+    """-> (snapped, original) segment lists for `<wav>.lab` (both empty when the file is missing), correct_label.py:40-87."""
+    lab_path = wav_path.replace(".wav", ".lab")
+    if not os.path.exists(lab_path):
+        return [], []
+    original = read_lab(lab_path)
+    return snap_segments(original, predicted_boundaries, snap_threshold), original
+
+
+def write_lab(wav_path, snapped_boundaries, out_path=None):
+    lab_path = wav_path.replace(".wav", ".lab") if out_path is None else out_path
+    with open(lab_path, "w") as f:
+        for start, end, label in snapped_boundaries:
+            f.write(f"{int(start * 1e7)} {int(end * 1e7)} {label}\n")
+
+
+def process_file(wav_path):
+    """correct_label.py:153-177 without the plotting: detect (or reuse `<wav>_boundary.txt`), snap, rewrite the `.lab`."""
+    y, sr = A.read_wav(wav_path)
+    if sr != 16000:
+        raise ValueError("correct_label: 16 kHz input only (librosa.load's soxr resampling is not restated)")
+    y = y.astype(np.float32)
+    txt = wav_path.replace(".wav", "_boundary.txt")
+    if os.path.exists(txt):
+        with open(txt) as f:
+            predicted = [float(line.strip()) for line in f if line.strip()]
+    else:
+        predicted = detect_boundaries(y, sr)[0]
+    snapped, _ = correct_lab_boundaries(wav_path, predicted)
+    write_lab(wav_path, snapped)
+    if os.path.exists(txt):
+        os.remove(txt)
+    return snapped
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="Correct .lab timing boundaries from audio features.")
+    ap.add_argument("input_path", type=str, help="Path to .wav file or folder containing .wav files")
+    args = ap.parse_args(argv)
+    if os.path.isdir(args.input_path):
+        for f in sorted(os.listdir(args.input_path)):
+            if f.endswith(".wav"):
+                process_file(os.path.join(args.input_path, f))
+    else:
+        process_file(args.input_path)
+
+
+if __name__ == "__main__":
+    main()

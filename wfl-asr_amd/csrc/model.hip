@@ -55,6 +55,7 @@ struct Conv0Args {
   const float* gamma; const float* beta;
   int B, T0, C;
   double* cstats;
+  float* cpart;
   bf16_t* out; long lead; int P;
 };
 int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s);
@@ -840,7 +841,7 @@ struct Plan {
   long Rl[8];
   // byte offsets
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
-  long FA, FB, XG, gate, rtab, wstats, cstats, err, Xlo, Ylo, total;
+  long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, total;
 };
 
 static int wavlm_frames(const wfl_arch& a, int L) {
@@ -894,6 +895,7 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
     p.rtab = take((long)a.enc_heads * (2L * p.T + 1) * 4);
     p.wstats = take((long)B * 2 * 8);
     p.cstats = take((long)B * C * 2 * 8);
+    p.cpart = take(a.wavlm_group_norm ? (long)B * ((p.Tl[0] + 511) / 512) * C * 2 * 4 : 16);   // GroupNorm partials per 512-step block
   }
   p.X = take(p.R * p.d * 2);
   p.Y = take(p.R * p.d * 2);
@@ -1213,7 +1215,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       Conv0Args c{};
       c.wav = wav; c.ldw = ldw; c.L = L; c.wstats = wstats; c.w = m->conv0_w; c.bias = m->conv0_b;
       c.gamma = m->conv0_norm.g; c.beta = m->conv0_norm.b; c.B = B; c.T0 = p.Tl[0]; c.C = C;
-      c.cstats = (double*)(R.ws + p.cstats); c.out = F[0]; c.lead = p.leadl[0]; c.P = p.Pl[0];
+      c.cstats = (double*)(R.ws + p.cstats); c.cpart = (float*)(R.ws + p.cpart); c.out = F[0]; c.lead = p.leadl[0]; c.P = p.Pl[0];
       const int r = wfl_launch_conv0(c, a.wavlm_group_norm, R.s);
       if (r) return fail(r, "conv0 launch failed");
     }

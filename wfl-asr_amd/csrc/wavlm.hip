@@ -2,8 +2,8 @@
 //   * waveform statistics for Wav2Vec2FeatureExtractor's do_normalize   (HF feature_extraction_wav2vec2.py:78-97)
 //   * conv layer 0 of the feature encoder (Cin = 1, k = 10, stride 5) fused with its normalisation + GELU:
 //       "group" checkpoints (base / base-plus): GroupNorm(C groups) = per-channel statistics over ALL time steps
-//          of a clip -> pass 1 accumulates sum / sum-of-squares per (clip, channel) in fp64 atomics WITHOUT storing
-//          the 98 MB/clip activation, pass 2 recomputes the 10-tap conv (10 MACs) and writes GELU(GN(y)) once;
+//          of a clip -> pass 1 leaves sum / sum-of-squares per (clip, time block, channel), a reduce kernel adds the blocks up in
+//          a fixed order (no atomics: bit-identical from run to run) WITHOUT storing the 98 MB/clip activation, pass 2 recomputes the 10-tap conv (10 MACs) and writes GELU(GN(y)) once;
 //       "layer" checkpoints (large): conv + bias -> LayerNorm over channels -> GELU, one wave per time step.
 //     (HF modeling_wavlm.py:675-744, 772-782)
 //   * channel regrouping for the grouped positional conv (HF modeling_wavlm.py:48-90): [rows][d] -> [groups][rows][64]
@@ -12,18 +12,27 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------- waveform statistics
-__global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, long ldw, int L, double* __restrict__ stats) {
-  const int b = blockIdx.y;
+// One workgroup per clip, every partial sum added in a FIXED order (no atomics: the result is bit-identical from run to run)
+__global__ __launch_bounds__(1024) void wav_stats_kernel(const float* __restrict__ wav, long ldw, int L, double* __restrict__ stats) {
+  __shared__ double ps[16], pq[16];
+  const int b = blockIdx.x;
   const float* w = wav + (long)b * ldw;
   double s = 0.0, q = 0.0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+  for (long i = threadIdx.x; i < L; i += 1024) {
     const double v = w[i];
     s += v;
     q += v * v;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(stats + 2 * b, s); atomicAdd(stats + 2 * b + 1, q); }
+  if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = s; pq[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < 16; ++i) { ts += ps[i]; tq += pq[i]; }
+    stats[2 * b] = ts;
+    stats[2 * b + 1] = tq;
+  }
 }
 
 struct Conv0Args {
@@ -34,6 +43,7 @@ struct Conv0Args {
   const float* gamma; const float* beta;  // [C]
   int B, T0, C;
   double* cstats;                         // [B][C][2] (group mode)
+  float* cpart;                           // [B][time blocks][C][2] per-workgroup partial sums (group mode, pass 1)
   bf16_t* out; long lead; int P;          // frame rows [.., C]
 };
 
@@ -73,9 +83,9 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
         for (int j = 0; j < 10; ++j) { const float x = xs[t * 5 + j]; ya = fmaf(wa[j], x, ya); yb = fmaf(wb[j], x, yb); }
         sa += ya; qa += ya * ya; sb += yb; qb += yb * yb;
       }
-      double* st = p.cstats + ((long)b * p.C + c0) * 2;
-      atomicAdd(st, (double)sa); atomicAdd(st + 1, (double)qa);
-      atomicAdd(st + 2, (double)sb); atomicAdd(st + 3, (double)qb);
+      // partial sums of this time block; conv0_stats_reduce_kernel adds the blocks up in a fixed order (deterministic)
+      float* st = p.cpart + (((long)b * gridDim.x + blockIdx.x) * p.C + c0) * 2;
+      *(f32x4*)st = (f32x4){sa, qa, sb, qb};
     } else {
       const double* st = p.cstats + ((long)b * p.C + c0) * 2;
       const double ma = st[0] / p.T0, mb = st[2] / p.T0;
@@ -96,6 +106,19 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void conv0_stats_reduce_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ cstats) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    const float2 v = *(const float2*)(part + (((long)b * nblk + k) * C + c) * 2);
+    s += (double)v.x;
+    q += (double)v.y;
+  }
+  cstats[((long)b * C + c) * 2] = s;
+  cstats[((long)b * C + c) * 2 + 1] = q;
 }
 
 // "layer" mode: one wave per time step, 8 channels per lane (C <= 512), LayerNorm over channels, GELU
@@ -152,19 +175,17 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args p) {
 }
 
 int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s) {
-  if (wfl_launch_fill_i32((int*)stats, 4L * B, 0, s)) return -3;           // (a kernel, not a memset node: common.h)
-  int blocks = (L + 256 * 16 - 1) / (256 * 16);
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(wav_stats_kernel, dim3(blocks, B), dim3(256), 0, s, wav, ldw, L, stats);
+  hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(1024), 0, s, wav, ldw, L, stats);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s) {
   if (a.C % 8 || a.C > 512 || a.T0 <= 0) return -1;
   if (group_norm) {
-    if (wfl_launch_fill_i32((int*)a.cstats, 4L * a.B * a.C, 0, s)) return -3;
+    if (!a.cpart) return -1;
     dim3 grid((a.T0 + C0_TT - 1) / C0_TT, a.B);
     hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv0_stats_reduce_kernel, dim3((a.C + 255) / 256, a.B), dim3(256), 0, s, a.cpart, (int)grid.x, a.C, a.cstats);
     hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), 0, s, a);
   } else {
     int bx = (a.T0 + 3) / 4;
