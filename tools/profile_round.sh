@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collect the round's bench lines and rocprofv3 summaries on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh <tag>        -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
+# Counters are collected in their own runs (one --pmc set per pass, no trace domains besides the kernel trace).
+set -u
+TAG=${1:-round}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py"
+echo "== bench lines"
+timeout -k 10 400 $B > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err || exit 1
+timeout -k 10 300 $B --full-head --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_fullhead_b16.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 $B --full-head --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_fullhead_b64.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 $B --config-index 2 --steps 6 --warmup 2 --cpu-clips 2 --cpu-calls 3 > $OUT/bench_cfg3.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 $B --config-index 3 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg4.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 $B --config-index 4 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_fp8.json 2>> $OUT/bench.err || exit 1
+WFL_BENCH_FAKE_WORLD=1 timeout -k 10 200 $B --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-h2d > $OUT/bench_fake_world.json 2>> $OUT/bench.err || exit 1
+echo "== kernel stats"
+P="--steps 10 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks1 -o cfg2_inflight1 -- $B $P --inflight 1 > $OUT/ks1.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2 -o cfg2_inflight2 -- $B $P --inflight 2 > $OUT/ks2.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf -o fullhead_inflight1 -- $B $P --inflight 1 --full-head > $OUT/ksf.log 2>&1 || exit 1
+echo "== pmc"
+P4="--steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B $P4 > $OUT/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $B $P4 > $OUT/pmc_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B $P4 > $OUT/pmc_sq.log 2>&1 || exit 1
+echo "== lstm micro"
+(cd $ROOT/tools/micro && ./lstm_bench_stamps > $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 512 64 499 >> $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 384 64 1500 >> $OUT/lstm_step_breakdown.txt 2>&1)
+find $OUT -name "*.csv" | head -30
+echo done
