@@ -325,8 +325,8 @@ def main():
                 lnf, stats = (key >> 8) & 3, bool(key & 1024)
                 tf = lambda b: "true" if b else "false"
                 if kid in (1, 5, 6, 7):               # 6 = the tap-stationary conv mode, 7 = fp8 (e4m3) weights
-                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s%s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
-                                                                             tf(kid == 6), ", true" if kid == 7 else "")
+                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s, %s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
+                                                                               tf(kid == 6), tf(kid == 7))
                 if kid in (2, 3):
                     return "gemm256_kernel<%d, %s, %s, %d>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
                 return "gemm_bf16_kernel<%d, %s, %s>" % (acts[act], tf(glu), tf(f32))

@@ -208,3 +208,62 @@ def test_full_size_properties_cfg3_cfg4(idx, B, L):
     again = m.label(x, lang, threshold=0.5, want_logits=True)
     assert torch.equal(again.logits, full.logits) and torch.equal(again.ids, full.ids)
     m.check(B, L)
+
+
+def test_outlier_channels_through_the_folded_layernorm_path():
+    """A checkpoint whose residual stream carries massive activations: two channels of the positional table at +60 / -40 and a
+    common offset of +4 on all channels (real Whisper / WavLM states look like this; the synthetic O(1) weights never probe it).
+    Whisper-base dims, 2 layers + linear head so the CPU oracle finishes in seconds; the LayerNorm-folded GEMMs take their
+    statistics from the producing residual GEMM (one-pass E[x^2] - mean^2 over the bf16 hi halves), the stream itself is hi + lo."""
+    cfg = synth.baseline_config(1)
+    cfg["model"].update(whisper_model="local/whisper-base-2l", num_conformer_layers=1)
+    cfg["model"]["encoder_arch"] = dict(d_model=512, layers=2, heads=8, ffn=2048, n_mels=80, max_positions=1500)
+    labels = synth.make_labels(70)
+    sd_np = synth.make_state_dict(cfg, len(labels), seed=90)
+    pos = sd_np["encoder.embed_positions.weight"].copy()
+    pos += 4.0
+    pos[:, 7] += 60.0
+    pos[:, 300] -= 40.0
+    sd_np["encoder.embed_positions.weight"] = pos
+    m = BIOPhonemeTagger(cfg, labels)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.to("cuda").eval()
+    wav = synth.make_batch(7700, 1, 160000, seed=90)
+    lang = np.array([1], np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True, want_hidden=True)
+    enc_name, arch = resolve_encoder_arch(cfg["model"])
+    lg, of, hid = O.forward(torch.from_numpy(wav), torch.from_numpy(lang), O.to_torch_state_dict(sd_np), enc_name, arch,
+                            synth.head_config(cfg["model"]), return_hidden=True)
+    h_err = (out.hidden.cpu() - hid).abs()
+    err = (out.logits.cpu() - lg).abs()
+    assert float(h_err.max()) <= 0.08 and float(h_err.mean()) <= 0.012, (float(h_err.max()), float(h_err.mean()))
+    assert float(err.max()) <= 0.40 and float(err.mean()) <= 0.07, (float(err.max()), float(err.mean()))
+    ids_ref, maxp, arg, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
+    safe = margin > 0.4 * float(lg.std()) / 6.5
+    assert int((out.argmax.cpu().long() != arg)[safe].sum()) == 0
+
+
+def test_wavlm_labeler_exact_length_buckets_pipelined(tmp_path):
+    """WavLM rows are batched by exact length (the reference never pads WavLM input); the loop keeps two batches in flight.
+    Files of three lengths, batch_size 2: full, partial and single-row batches on both slots must equal the single-row loop."""
+    from cases import tiny_wavlm_config
+    from test_gpu_infer import _manual
+    d = tmp_path
+    cfg = tiny_wavlm_config(True, enable_bilstm=True)
+    cfg["output"]["save_dir"] = str(d / "save")
+    cfg["postprocess"] = {"median_filter": 1, "merge_segments": "right", "confidence_threshold": 0.3}
+    os.makedirs(cfg["output"]["save_dir"])
+    labels = synth.make_labels(5)
+    (d / "save" / "phonemes.txt").write_text("\n".join(labels) + "\n")
+    (d / "save" / "langs.txt").write_text("en,0\nja,1\n")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, len(labels), seed=65).items()}
+    os.makedirs(d / "wavs")
+    paths = []
+    for i, s in enumerate([1.0, 1.0, 2.5, 1.0, 0.7, 2.5, 1.0]):
+        p = str(d / "wavs" / f"w{i}.wav")
+        A.write_wav(p, synth.make_clip(960 + i, int(16000 * s), seed=65) * 0.8, 16000)
+        paths.append(p)
+    lab = I.Labeler(cfg, sd, device="cuda", batch_size=2)
+    got = lab.label_files(paths, lang_id=0, confidence_threshold=0.3, verbose=False)
+    for path, segs in zip(paths, got):
+        assert segs == _manual(lab, path, 0, 0.3), path

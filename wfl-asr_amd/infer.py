@@ -152,21 +152,57 @@ class Labeler:
         finish(1)
 
     def _forward_items_by_length(self, items, lang_id, threshold):
-        """WavLM: the frame count follows the clip length, so rows are grouped by exact length."""
+        """WavLM: the frame count follows the clip length and the reference never pads WavLM input (padding would change the
+        GroupNorm statistics and the unmasked attention), so a batch holds rows of exactly equal length.  Same pipeline as
+        `_run_batches`: two batches in flight on two streams / workspace slots, pinned staging both ways, the status word read
+        with the tags."""
         out = [None] * len(items)
         by_len = {}
         for i, x in enumerate(items):
             by_len.setdefault(len(x), []).append(i)
-        for n, idxs in by_len.items():
-            for s in range(0, len(idxs), self.batch_size):
-                sel = idxs[s:s + self.batch_size]
-                wav = torch.from_numpy(np.stack([items[i] for i in sel])).to(self.device)
+        jobs = [(n, idxs[s:s + self.batch_size]) for n, idxs in by_len.items() for s in range(0, len(idxs), self.batch_size)]
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
+        pending = [None, None]
+        pin_in, pin_out = [None, None], [None, None]
+
+        def finish(slot):
+            job = pending[slot]
+            if job is None:
+                return
+            sel, T, ev = job
+            ev.synchronize()
+            nn = len(sel) * T
+            blob = pin_out[slot].numpy()
+            raise_on_status(int(blob[4 * nn]))
+            ids = blob[0:nn].reshape(len(sel), T)
+            offs = blob[2 * nn:4 * nn].view(np.float32).reshape(len(sel), T, 2)
+            for j, i in enumerate(sel):
+                out[i] = (ids[j].copy(), offs[j].copy())
+            pending[slot] = None
+
+        for k, (n, sel) in enumerate(jobs):
+            slot = k % 2
+            finish(slot)
+            T = self.model.num_frames(n)
+            need_in, need_out = len(sel) * n, len(sel) * T * 4 + 1
+            if pin_in[slot] is None or pin_in[slot].numel() < need_in:
+                pin_in[slot] = torch.empty(need_in, dtype=torch.float32).pin_memory()
+            if pin_out[slot] is None or pin_out[slot].numel() < need_out:
+                pin_out[slot] = torch.empty(need_out, dtype=torch.int32).pin_memory()
+            host = pin_in[slot][:need_in].view(len(sel), n)
+            for j, i in enumerate(sel):
+                host[j] = torch.from_numpy(np.ascontiguousarray(items[i]))
+            with torch.cuda.stream(self._streams[slot]):
+                wav = host.to(self.device, non_blocking=True)
                 res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold,
-                                       average_languages=lang_id is None)
-                ids, offs = res.ids.cpu().numpy(), res.offsets.cpu().numpy()
-                raise_on_status(int(res.status.item()))
-                for j, i in enumerate(sel):
-                    out[i] = (ids[j], offs[j])
+                                       average_languages=lang_id is None, slot=slot)
+                pin_out[slot][:need_out].copy_(res.packed, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._streams[slot])
+            pending[slot] = (sel, T, ev)
+        finish(0)
+        finish(1)
         return out
 
     def _lang_name(self, lang_id):
