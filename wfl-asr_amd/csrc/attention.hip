@@ -12,6 +12,7 @@
 // transposed copy of V ever exists.
 // q is pre-scaled by head_dim^-1/2 * log2(e) at weight-pack time, so the softmax is exp2(s - max).
 #include "common.h"
+#include <cstdlib>
 
 #define KT 64          // keys per tile
 // V tile rows are HD*2 + 32 bytes apart: the 8 key rows x 32 bytes one 32-lane half of a ds_read_b64_tr_b16 touches then
@@ -303,6 +304,13 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
 
 int wfl_launch_attention_big(const AttnArgs& a, hipStream_t s);   // attention_big.hip: head_dim 384 / 512 / 640
 
+// WFL_ATTN_VARIANT=1 selects round 1's kernel (attention_big.hip) for head_dim 384 (A/B runs)
+static int attn_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WFL_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldv % 8 || a.ldo % 4 || a.T <= 0 || !a.V) return -1;
   const int hd = a.d / a.heads;
@@ -318,8 +326,11 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
     case 32: return launch_attn<32, 2, true, false>(a, s);
     case 64: return launch_attn<64, 2, true, false>(a, s);
     case 128: return launch_attn<128, 2, true, false>(a, s);
-    case 256: return launch_attn<256, 1, false, false>(a, s);
-    case 384: case 512: case 640: return wfl_launch_attention_big(a, s);
+    case 256: return launch_attn<256, 1, false, false>(a, s);   // (QT = 2 with two tiles in LDS measured slower: 166 vs 124 us at cfg2 size)
+    // head_dim 384 (Whisper-small's Conformer heads): 32 queries per wave with Q in registers (506 VGPRs, one wave per SIMD) halves the
+    // K / V tile traffic per query against attention_big's 16: 845 vs 2 635 us at 64 x 1500 frames (tools/attn_bench.py)
+    case 384: return attn_variant() == 1 ? wfl_launch_attention_big(a, s) : launch_attn<384, 2, false, false>(a, s);
+    case 512: case 640: return wfl_launch_attention_big(a, s);
   }
   return -4;   // unsupported head_dim
 }
