@@ -6,7 +6,7 @@ error against the fp32 run.  Flags (any combination, comma separated on the comm
   a     the input of every Linear / Conv rounded to bf16 (what a bf16 MFMA operand is)
   r     the residual stream rounded to bf16 after every residual add (and the stem output)
   attn  q, k, v and the softmax probabilities rounded to bf16
-  r_stem / r_encln / r_lang / r_ln1   the residual stream rounded only at that one place
+  r_stem / r_encln / r_lang / r_ln1 / r_enc<i> / r_conf<i>   the residual stream rounded only at that place (encoder layer i, Conformer block i)
   cls   the classifier's input and weight rounded to bf16 (w / a leave the classifier alone)
   wenc / whead   weights of the encoder / of the head (classifier excepted) only
 usage: python tests/study_quant.py [clips] flags [flags ...]     e.g.  python tests/study_quant.py 1 w a r attn w,a,r,attn
@@ -84,10 +84,10 @@ def forward(q, wav, lang, sd, arch, hc):
         k = lin(q, h, sd, lp + "self_attn.k_proj").view(B, T, heads, hd).transpose(1, 2)
         v = lin(q, h, sd, lp + "self_attn.v_proj").view(B, T, heads, hd).transpose(1, 2)
         a = attn(q, qq, k, v).transpose(1, 2).reshape(B, T, d)
-        x = q.r(x + lin(q, a, sd, lp + "self_attn.out_proj"))
+        x = q.r(x + lin(q, a, sd, lp + "self_attn.out_proj"), f"enc{i}")
         h = O._ln(x, sd, lp + "final_layer_norm")
         h = F.gelu(lin(q, h, sd, lp + "fc1"))
-        x = q.r(x + lin(q, h, sd, lp + "fc2"))
+        x = q.r(x + lin(q, h, sd, lp + "fc2"), f"enc{i}")
     x = q.r(O._ln(x, sd, p + "layer_norm"), "encln")
     hidden = x
     e = sd["lang_emb.weight"][lang][:, None, :].expand(-1, T, -1)
@@ -101,7 +101,7 @@ def forward(q, wav, lang, sd, arch, hc):
             h = O._ln(x, sd, pp + ".net.0")
             return lin(q, F.gelu(lin(q, h, sd, pp + ".net.1")), sd, pp + ".net.4")
 
-        x = q.r(x + 0.5 * ff(x, cp + "ff1"))
+        x = q.r(x + 0.5 * ff(x, cp + "ff1"), f"conf{i}")
         qkv = F.linear(q.a(x, cp), q.w(sd[cp + "self_attn.in_proj_weight"], cp), sd[cp + "self_attn.in_proj_bias"])
         qq, k, v = qkv.chunk(3, dim=-1)
         qq = qq.view(B, T, ch, chd).transpose(1, 2) * chd ** -0.5
@@ -115,8 +115,8 @@ def forward(q, wav, lang, sd, arch, hc):
         h = F.batch_norm(h, sd[cp + "conv.3.running_mean"], sd[cp + "conv.3.running_var"], sd[cp + "conv.3.weight"],
                          sd[cp + "conv.3.bias"], False, 0.0, 1e-5)
         h = conv(q, F.gelu(h), sd, cp + "conv.5").transpose(1, 2)
-        x = q.r(x + h)
-        x = q.r(x + 0.5 * ff(x, cp + "ff2"))
+        x = q.r(x + h, f"conf{i}")
+        x = q.r(x + 0.5 * ff(x, cp + "ff2"), f"conf{i}")
     logits = lin(q, x, sd, "classifier")
     return logits, hidden
 

@@ -18,11 +18,12 @@ DRV = '''
 #include "common.h"
 extern "C" int diag_gemm(const void* A, long lda, int cin, long tap_stride, const void* W, int M, int N, int K, int P, int T,
                          void* Cout, long ldc, long c_lead, const float* bias, const void* res, int act, unsigned long long* stamps,
-                         const float* ln_s, void* stream) {
+                         const float* ln_s, void* stream, const void* res_lo, void* c_lo, float* stats_out) {
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.cin = cin > 0 ? cin : K; g.tap_stride = tap_stride; g.W = (const bf16_t*)W;
   g.M = M; g.N = N; g.K = K; g.n_valid = N; g.P = P; g.T = T; g.C = Cout; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = P;
   g.bias = bias; g.res = (const bf16_t*)res; g.ldres = ldc; g.alpha = 1.f; g.act = act; g.stamps = stamps; g.ln_s = ln_s; g.ln_eps = 1e-5f;
+  g.res_lo = (const bf16_t*)res_lo; g.c_lo = (bf16_t*)c_lo; g.stats_out = stats_out;
   return wfl_launch_gemm(g, (hipStream_t)stream);
 }
 '''
@@ -61,7 +62,8 @@ def main():
             path = build(name, fl)
         lib = C.CDLL(path)
         lib.diag_gemm.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                  C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                                  C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
         libs[name] = lib
     B, T, P, lead = 16, 1500, 1520, 16
     M = B * P
@@ -75,6 +77,10 @@ def main():
         W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         Cb = torch.zeros(R, N, dtype=torch.bfloat16, device="cuda")
         Rs = (torch.randn(R, N, device="cuda")).to(torch.bfloat16)
+        lo_mode = bool(os.environ.get("LAB_LO")) and res            # residual stream as hi + lo (+ statistics with LAB_STATS)
+        Rlo = (torch.randn(R, N, device="cuda") * 0.003).to(torch.bfloat16) if lo_mode else None
+        Clo = torch.zeros(R, N, dtype=torch.bfloat16, device="cuda") if lo_mode else None
+        Sts = torch.zeros(R * 8, dtype=torch.float32, device="cuda") if (res and os.environ.get("LAB_STATS") and N <= 1024) else None
         bias = torch.randn(N, device="cuda")
         stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -89,7 +95,9 @@ def main():
                                  C.c_void_p(Cb.data_ptr()), N, lead, C.c_void_p(bias.data_ptr()),
                                  C.c_void_p(Rs.data_ptr()) if res else None, act,
                                  C.c_void_p(stamps.data_ptr()) if with_stamps else None,
-                                 C.c_void_p(ln_s.data_ptr()) if ln else None, st)
+                                 C.c_void_p(ln_s.data_ptr()) if ln else None, st,
+                                 C.c_void_p(Rlo.data_ptr()) if lo_mode else None, C.c_void_p(Clo.data_ptr()) if lo_mode else None,
+                                 C.c_void_p(Sts.data_ptr()) if Sts is not None else None)
 
         times = {n: [] for n in libs}
         # independent reference for 64 rows spread over the run (fp32 matmul of the bf16 operands)
@@ -103,6 +111,8 @@ def main():
             ref = torch.nn.functional.gelu(ref)
         if res:
             ref = ref + Rs[lead + ridx].float()
+            if lo_mode:
+                ref = ref + Rlo[lead + ridx].float()
         for rnd in range(5):
             for n, lib in libs.items():
                 for _ in range(2):

@@ -127,6 +127,31 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
   };
 
+  // BIAS: the slice of the relative-position table a key tile needs -- offsets key - query for this workgroup's 4 * QT * 16 queries
+  // and the tile's 64 keys, 64 + 4 * QT * 16 - 1 entries -- is staged in LDS one tile ahead (it rides on the tile's barrier); round 1
+  // gathered every score's entry from global memory inside the loop (the BIAS kernel ran at half the plain kernel's rate)
+  constexpr int NQW = 4 * QT * 16;                       // queries per workgroup
+  constexpr int BT = KT + NQW;                           // table entries per tile (one spare)
+  float* btab = (float*)(smem + (PREFETCH ? 2 : 1) * TILE_BYTES);   // [2][BT]
+  const int qwg0 = qb * NQW;
+  const float* tabc = BIAS ? p.bias + (long)h * (2 * p.T - 1) + (p.T - 1) : nullptr;
+  auto stage_bias = [&](int kt) {
+    if (BIAS && tid < BT - 1) {
+      int off = kt * KT - qwg0 - (NQW - 1) + tid;        // key - query for entry tid
+      off = off < -(p.T - 1) ? -(p.T - 1) : (off > p.T - 1 ? p.T - 1 : off);
+      btab[(kt & 1) * BT + tid] = tabc[off];
+    }
+  };
+  float gq[QT];
+  if (BIAS) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      int q = q0 + qt * 16 + c;
+      q = q < p.T ? q : p.T - 1;
+      gq[qt] = p.gate[((long)b * p.heads + h) * p.T + q];
+    }
+    stage_bias(0);
+  }
   if (PREFETCH) {
     load_tile(0);
     store_tile();                        // tile 0 -> buffer 0
@@ -164,21 +189,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     if (BIAS) {
       // WavLM gated relative position bias (HF modeling_wavlm.py:167-180, 243-271): score += gate[b,h,q] * table[h][k-q],
       // table = rel_attn_embed[bucket(k - q)][h] * log2(e), one row of 2T-1 entries per head, built at load time
-      const float* tab = p.bias + (long)h * (2 * p.T - 1) + (p.T - 1);
+      const float* bt = btab + (kt & 1) * BT + (NQW - 1) - (wid * (QT * 16) + c) + g * 4;   // entry of (key 0 of the tile, this lane's query 0)
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        int q = q0 + qt * 16 + c;
-        q = q < p.T ? q : p.T - 1;
-        const float gq = p.gate[((long)b * p.heads + h) * p.T + q];
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int key = kt * KT + kk * 16 + g * 4 + e;
-            key = key < p.T ? key : p.T - 1;
-            st[qt][kk][e] = fmaf(gq, tab[key - q], st[qt][kk][e]);
-          }
-      }
+          for (int e = 0; e < 4; ++e) st[qt][kk][e] = fmaf(gq[qt], bt[kk * 16 + e - qt * 16], st[qt][kk][e]);
     }
     if (kt * KT + KT > p.T) {            // last tile: keys >= T do not exist
 #pragma unroll
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       Vs = Ks + KT * HD * 2;
       store_tile();
       if (kt + 2 < ntiles) load_tile(kt + 2);
+      stage_bias(kt + 1);
       __syncthreads();
     }
   }
@@ -290,7 +308,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
 template <int HD, int QT, bool PREFETCH, bool BIAS>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
-  constexpr int lds = (PREFETCH ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32));
+  static_assert(!BIAS || PREFETCH, "the bias table slice is staged on the prefetch barrier");
+  constexpr int lds = (PREFETCH ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32)) + (BIAS ? 2 * (KT + 4 * QT * 16) * 4 : 0);
   auto k = attn_kernel<HD, QT, PREFETCH, BIAS>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {

@@ -32,8 +32,12 @@
 #include <type_traits>
 
 #define SBK 32
-#define SNST 4
-#define SNCU 256
+#ifndef SNST
+#define SNST 4         // ring depth (stages): SNST - 1 stages in flight ahead of the one being computed.  The code is written for 3 .. 6;
+#endif                 // measured (tools/gemm_lab.py r4=-DSNST=4 r5=-DSNST=5): 5 stages change nothing (0.611 vs 0.612 us per K step at
+                       // K = 2048), so the 0.12 us the operand DMA adds to a K step is not latency a deeper ring could hide; neither is
+                       // it the place the LDS-DMA instructions are issued from (WFL_DMA_IN_C = 1, 2: same time).  What is left is the
+                       // issue cost of the 28 one-KiB LDS-DMA instructions themselves: the per-CU L2 -> LDS ceiling.
 
 typedef __attribute__((address_space(1))) const void* sgptr_t;
 typedef __attribute__((address_space(3))) void* slptr_t;
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   const bf16_t* w_src[2];
   const char* w8_src = nullptr;                     // W8: this lane's 16 source bytes of the wave's ONE weight piece (32 rows x 32 bytes)
   int pv = blockIdx.x, pkt = 0, issued = 0;
+  int islot = 0;                                    // ring slot of the next stage to issue (= issued % SNST)
   int ptap_k = 0;                                   // position inside the current tap (conv GEMMs), elements
   long pbase = 0;                                   // tap * tap_stride
   int pcc = 0, ptap = 0, pccg = 0;                  // CONV: channel chunk / tap being issued; chunks issued so far (buffer parity)
@@ -144,7 +149,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   set_src(pv);
   auto issue_stage = [&]() __attribute__((always_inline)) {                        // the DMA of stage (pv, pkt); advances the position inside the tile
     if (CONV) {
-      char* base = smem + (issued & (SNST - 1)) * STB;
+      char* base = smem + islot * STB;
+      islot = islot + 1 == SNST ? 0 : islot + 1;
       if (ptap == 0) {                               // first tap of a channel chunk: its extended frame tile rides along
         char* ab = smem + AOFF + (pccg & 1) * AEXT;
         sglds(a_src[0] + pcc * SBK, ab + xg0 * 1024);
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       return;
     }
     const long koff = pbase + ptap_k;
-    char* base = smem + (issued & (SNST - 1)) * STB;
+    char* base = smem + islot * STB;
+    islot = islot + 1 == SNST ? 0 : islot + 1;
     sglds(a_src[0] + koff, base + xg0 * 1024);
     if (two_x) sglds(a_src[1] + koff, base + xg0 * 1024 + 1024);
     if (W8) {
@@ -171,6 +178,36 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     ++pkt;
     ptap_k += SBK;
     if (ptap_k == p.cin) { ptap_k = 0; pbase += p.tap_stride; }
+  };
+  // Steady-state variant: the frame pieces (and the weight pieces that are not deferred) now, the NDC deferred weight pieces from
+  // inside the MFMA block of the same step (issue_deferred).  An LDS-DMA instruction issued right behind a burst of ds_reads costs
+  // the wave 100-185 cycles, one issued between MFMAs about 60 (MI355X_MICROARCH.md, cycle constants): with all four in the L slot
+  // the L slot (~750 cycles) was twice the C slot (24 MFMAs = 384) and set the K step.
+  int d_pkt = 0;
+  char* d_base = nullptr;
+  auto issue_stage_split = [&](auto ndc_c) __attribute__((always_inline)) {
+    constexpr int NDC = decltype(ndc_c)::value;
+    const long koff = pbase + ptap_k;
+    char* base = smem + islot * STB;
+    islot = islot + 1 == SNST ? 0 : islot + 1;
+    sglds(a_src[0] + koff, base + xg0 * 1024);
+    if (two_x) sglds(a_src[1] + koff, base + xg0 * 1024 + 1024);
+    if (W8) {
+      if (NDC == 0) sglds((const bf16_t*)(w8_src + pkt * SBK), base + WOFF + wid * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2 - NDC; ++i) sglds(w_src[i] + pkt * SBK, base + WOFF + wid * 2048 + i * 1024);
+    }
+    d_pkt = pkt; d_base = base;
+    ++issued;
+    ++pkt;
+    ptap_k += SBK;
+    if (ptap_k == p.cin) { ptap_k = 0; pbase += p.tap_stride; }
+  };
+  auto issue_deferred = [&](int j, auto ndc_c) __attribute__((always_inline)) {     // j-th deferred weight piece (j < NDC)
+    constexpr int NDC = decltype(ndc_c)::value;
+    if (W8) sglds((const bf16_t*)(w8_src + d_pkt * SBK), d_base + WOFF + wid * 1024);
+    else sglds(w_src[2 - NDC + j] + d_pkt * SBK, d_base + WOFF + wid * 2048 + (2 - NDC + j) * 1024);
   };
   auto prefetch_one = [&]() __attribute__((always_inline)) {                       // issue the next stage of the stream, if there is one
     if (pv >= ntiles) return;
@@ -186,24 +223,21 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   auto wait_stage = [&](int need, bool with_stores) __attribute__((always_inline)) {
     const int younger = issued - need - 1;
     if (younger < 0) return;                        // no such stage (end of the stream)
-    if (CONV) {
-      // two weight-tile DMAs per wave and stage; the extended frame tile's DMAs (one stage in `taps`) are not counted: a
-      // smaller count only waits for more, and they are issued taps - 3 steps before their first read
-      if (younger >= 2) { if (with_stores) wait_vm<4 + NSTORE>(); else wait_vm<4>(); }
-      else if (younger == 1) { if (with_stores) wait_vm<2 + NSTORE>(); else wait_vm<2>(); }
-      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
-      return;
-    }
-    constexpr int L2X = W8 ? 3 : 4, L1X = W8 ? 2 : 3;     // DMA pieces per wave and stage (two / one frame pieces + weight pieces)
-    if (two_x) {
-      if (younger >= 2) { if (with_stores) wait_vm<2 * L2X + NSTORE>(); else wait_vm<2 * L2X>(); }
-      else if (younger == 1) { if (with_stores) wait_vm<L2X + NSTORE>(); else wait_vm<L2X>(); }
-      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
-    } else {
-      if (younger >= 2) { if (with_stores) wait_vm<2 * L1X + NSTORE>(); else wait_vm<2 * L1X>(); }
-      else if (younger == 1) { if (with_stores) wait_vm<L1X + NSTORE>(); else wait_vm<L1X>(); }
-      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }
-    }
+    // DMA pieces per wave and stage: CONV two weight pieces (the extended frame tile's pieces, one stage in `taps`, are not counted:
+    // a smaller count only waits for more, and they are issued taps - 3 steps before their first read); else two / one frame
+    // pieces + the weight pieces
+    constexpr int L2X = CONV ? 2 : (W8 ? 3 : 4), L1X = CONV ? 2 : (W8 ? 2 : 3);
+    static_assert(SNST >= 3 && SNST <= 6, "ring depth");
+#define WFL_WAITY(L)                                                                              \
+    do {                                                                                          \
+      if (SNST >= 6 && younger >= 4) { if (with_stores) wait_vm<4 * (L) + NSTORE>(); else wait_vm<4 * (L)>(); }       \
+      else if (SNST >= 5 && younger >= 3) { if (with_stores) wait_vm<3 * (L) + NSTORE>(); else wait_vm<3 * (L)>(); }  \
+      else if (younger >= 2) { if (with_stores) wait_vm<2 * (L) + NSTORE>(); else wait_vm<2 * (L)>(); }              \
+      else if (younger == 1) { if (with_stores) wait_vm<(L) + NSTORE>(); else wait_vm<(L)>(); }                      \
+      else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }                                                \
+    } while (0)
+    if (CONV || two_x) WFL_WAITY(L2X); else WFL_WAITY(L1X);
+#undef WFL_WAITY
   };
 
   // ---- fragment addressing.  Weight-tile row feeding MFMA row i of column tile v is channel
@@ -390,10 +424,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 
 #define SSB() __builtin_amdgcn_sched_barrier(0)
   bf16x8 fw[4], fx[MT];
-  int s = 0;                                         // global K-step counter (ring slot = s & 3)
+  int s = 0;                                         // global K-step counter
+  int rslot = 0;                                     // its ring slot (= s % SNST)
   int ctap = 0, ccg = 0;                              // CONV: tap of the step being computed; chunks finished (buffer parity)
   auto read_frags = [&]() __attribute__((always_inline)) {
-    const char* sb = smem + (s & (SNST - 1)) * STB;
+    const char* sb = smem + rslot * STB;
     if (W8) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -421,12 +456,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   };
   // The MFMAs of one K step; with a folded LayerNorm, wave wq of a group also sums the frame fragments u = wq and wq + 4
   // (v_dot2c_f32_bf16: sum and sum of squares), issued right behind that tile's MFMAs so they run in the MFMAs' shadow.
-  auto mma_all = [&]() __attribute__((always_inline)) {
+  auto mma_all = [&](auto ndc_c) __attribute__((always_inline)) {
+    constexpr int NDC = decltype(ndc_c)::value;      // deferred weight pieces to issue between the MFMAs (0: none)
     const bf16x2 one2 = {(bf16_t)1.0f, (bf16_t)1.0f};
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
+      if (NDC >= 1 && u == 1) { __builtin_amdgcn_sched_barrier(0); issue_deferred(0, ndc_c); __builtin_amdgcn_sched_barrier(0); }
+      if (NDC >= 2 && u == 3) { __builtin_amdgcn_sched_barrier(0); issue_deferred(1, ndc_c); __builtin_amdgcn_sched_barrier(0); }
       if (LNF == 1) {
         if ((u & 3) == wq) {                         // wave-uniform
 #pragma unroll
@@ -466,55 +504,66 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     int m0, n0;
     tile_of(tv, m0, n0);
     const bool last_tile = tv + G >= ntiles;
-    // One K step, general form: used for the first two steps of a tile (the previous tile's epilogue and its stores sit in
-    // the vmcnt queue) and the last four (the stream crosses into the next tile, or ends).
+    // One K step, general form: used for the first SNST - 2 steps of a tile (the previous tile's epilogue and its stores sit in
+    // the vmcnt queue: the stages issued before them are 0 .. SNST - 2) and the last SNST (the stream crosses into the next tile,
+    // or ends).
     auto step_general = [&](int kt, auto first_c) __attribute__((always_inline)) {
       if (decltype(first_c)::value && have_prev) epilogue(pm0, pn0);
       read_frags();
       prefetch_one();
-      if (grp) wait_stage(s + 1, have_prev && kt < 2);
+      if (grp) wait_stage(s + 1, have_prev && kt < SNST - 2);
       __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
       SSB();
-      mma_all();
+      mma_all(std::integral_constant<int, 0>{});
       if (LNF == 1 && kt == nk - 1) ln_publish();
       SSB();
-      if (!grp) wait_stage(s + 1, have_prev && kt < 2);
+      if (!grp) wait_stage(s + 1, have_prev && kt < SNST - 2);
       if (LNF == 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // the statistics are in LDS before the barrier
       if (LNF == 1 || !(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
       SSB();
       ++s;
+      rslot = rslot + 1 == SNST ? 0 : rslot + 1;
     };
-    // Steady state, kt in [2, nk - 5]: the stage being issued (kt + 3) and the two awaited next lie inside this tile and
-    // nothing but operand DMA is in the queue, so the waits are constants.  One copy per wave group (no per-step branches).
+    // Steady state, kt in [SNST - 2, nk - SNST - 1]: the stage being issued (kt + SNST - 1) and the ones awaited next lie inside
+    // this tile and nothing but operand DMA is in the queue, so the waits are constants: SNST - 2 stages stay in flight behind the
+    // awaited one.  One copy per wave group (no per-step branches).
     auto steps_steady = [&](auto grp_c) __attribute__((always_inline)) {
       constexpr bool GRP1 = decltype(grp_c)::value;
       constexpr int NL = CONV ? 2 : ((MT == 8 || !GRP1) ? (W8 ? 3 : 4) : (W8 ? 2 : 3));
-      for (int kt = 2; kt <= nk - 5; ++kt) {
+#ifndef WFL_DMA_IN_C
+#define WFL_DMA_IN_C 0     // (measured neutral at 1 and 2: tools/gemm_lab.py)
+#endif
+      constexpr int NDC = CONV ? 0 : (W8 ? (WFL_DMA_IN_C > 1 ? 1 : WFL_DMA_IN_C) : WFL_DMA_IN_C);   // weight pieces issued inside the C slot
+      const std::integral_constant<int, NDC> ndc_c{};
+      for (int kt = SNST - 2; kt <= nk - SNST - 1; ++kt) {
 #ifndef WFL_ABL_NOLDS          // diagnostic builds (tools/gemm_lab.py): no fragment reads / no operand DMA in the steady loop
         read_frags();
 #endif
 #ifndef WFL_ABL_NOSTAGE
-        issue_stage();
+        if (CONV) issue_stage(); else issue_stage_split(ndc_c);
 #else
         ++issued; ++pkt; if (CONV) { if (++ptap == ntaps) { ptap = 0; ++pcc; ++pccg; } }
 #endif
-        if (GRP1) wait_vm<2 * NL>();
+        // group 1 waits before the barrier: stage kt+2 is out in full, stage kt+3 only with its L-slot pieces so far
+        if (GRP1) wait_vm<(SNST - 2) * NL - NDC>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         SSB();
-        mma_all();
+        mma_all(ndc_c);
         SSB();
-        if (!GRP1) wait_vm<2 * NL>();
+        if (!GRP1) wait_vm<(SNST - 2) * NL>();
         __builtin_amdgcn_s_barrier();
         SSB();
         ++s;
+        rslot = rslot + 1 == SNST ? 0 : rslot + 1;
       }
     };
     step_general(0, std::true_type{});
-    step_general(1, std::false_type{});
+#pragma unroll
+    for (int kt = 1; kt < SNST - 2; ++kt) step_general(kt, std::false_type{});
     if (grp) steps_steady(std::true_type{}); else steps_steady(std::false_type{});
-    for (int kt = nk - 4 > 2 ? nk - 4 : 2; kt < nk; ++kt) step_general(kt, std::false_type{});
+    for (int kt = nk - SNST > SNST - 2 ? nk - SNST : SNST - 2; kt < nk; ++kt) step_general(kt, std::false_type{});
     pm0 = m0; pn0 = n0;
     have_prev = true;
   }
@@ -566,8 +615,10 @@ static bool wfl_gemm_stream_conv(const GemmArgs& a) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("WFL_GEMM_NO_CONV"); off = e && atoi(e) ? 1 : 0; }
   if (off) return false;
-  return a.cin < a.K && a.K % a.cin == 0 && a.K / a.cin <= 32 && a.tap_stride == a.lda && a.cin % SBK == 0 && !a.res && !a.ln_s &&
-         !a.stats_out;
+  // (at least SNST - 1 taps: a chunk's extended frame tile is issued SNST - 1 stages before its first tap and overwrites the buffer of
+  //  the chunk before last, whose last tap must have been read by then)
+  return a.cin < a.K && a.K % a.cin == 0 && a.K / a.cin <= 32 && a.K / a.cin >= SNST - 1 && a.tap_stride == a.lda && a.cin % SBK == 0 &&
+         !a.res && !a.ln_s && !a.stats_out;
 }
 
 // The launches this kernel takes (everything else stays with gemm256 / gemm).

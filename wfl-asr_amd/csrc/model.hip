@@ -121,7 +121,7 @@ struct Lin {
 struct LNp { float* g = nullptr; float* b = nullptr; };
 
 struct EncLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2, qkv_ln, fc1_ln; };   // *_ln: the LayerNorm in front folded in
-struct WavlmLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2; float *w8 = nullptr, *b8 = nullptr, *cst = nullptr; };
+struct WavlmLayer { LNp ln1, ln2; Lin qkv, out, fc1, fc2, fc1_ln; float *w8 = nullptr, *b8 = nullptr, *cst = nullptr; };
 struct ConfLayer {
   LNp ff1_ln, ff2_ln, ln1, ln2;
   Lin ff1_a, ff1_b, ff2_a, ff2_b, qkv, out, pw1, conv, pw2, ff1_a_ln, ff2_a_ln;
@@ -608,6 +608,11 @@ static int finalize_wavlm(wfl_model* m, Packer& P) {
     }
     L.out = P.linear(p + "attention.out_proj", d, d);
     L.fc1 = P.linear(p + "feed_forward.intermediate_dense", a.enc_ffn, d);
+    // (stable layers: final_layer_norm could fold into fc1 like Whisper's; measured on cfg3 it costs more in the residual GEMM's
+    //  statistics epilogue -- four 256-column tiles at d = 1024 -- and the folded fc1 than the LayerNorm launch it saves:
+    //  GEMM family +1.2 ms, LayerNorm -0.84 ms per 64 x 10 s step.  Set WFL_WAVLM_LN_FOLD=1 to try it.)
+    if (a.wavlm_stable_layer_norm && getenv("WFL_WAVLM_LN_FOLD") && atoi(getenv("WFL_WAVLM_LN_FOLD")))
+      L.fc1_ln = P.linear_ln(p + "feed_forward.intermediate_dense", a.enc_ffn, d, p + "final_layer_norm");
     L.fc2 = P.linear(p + "feed_forward.output_dense", d, a.enc_ffn);
     if (const HostTensor* w8 = P.get(p + "attention.gru_rel_pos_linear.weight", {8, hd})) L.w8 = P.upload(w8->data);
     if (const HostTensor* b8 = P.get(p + "attention.gru_rel_pos_linear.bias", {8})) L.b8 = P.upload(b8->data);
@@ -958,6 +963,7 @@ struct Runner {
     return (bf16_t*)(ws + (i == 0 ? p.Xlo : p.Ylo) + ((const char*)ptr - (ws + (i == 0 ? p.X : p.Y))));
   }
   const bf16_t* lo_in(const void* ptr) const { const int i = lo_idx(ptr); return (i >= 0 && lo_ok[i]) ? lo_of(ptr) : nullptr; }
+  bool next_stats = false;      // the next gemm() (a residual launch) feeds a LayerNorm-folded GEMM: have it emit the row statistics
   bool next_lo_out = false;     // the next gemm() produces a residual-stream tensor: keep its low half
   bool next_acc_f32 = false;    // the next gemm() (fp32 output) adds to what is there
   double next_flops = -1.0;     // >= 0: algorithmic FLOPs to book for the next gemm() instead of 2 M N K
@@ -994,8 +1000,10 @@ struct Runner {
     next_lo_out = next_acc_f32 = false;
     next_flops = -1.0;
     if (C == stats_for) stats_for = nullptr;                       // the rows they describe are being overwritten
-    if (res && !out_f32 && !glu && act == WFL_ACT_NONE && ldc == p.d && W.n_valid == p.d && c_lead == p.lead && c_pitch == p.P &&
-        P == p.P && ln_fold_mode() == 1 && !W.w8) {
+    const bool want_stats = next_stats;
+    next_stats = false;
+    if (want_stats && res && !out_f32 && !glu && act == WFL_ACT_NONE && ldc == p.d && W.n_valid == p.d && c_lead == p.lead &&
+        c_pitch == p.P && P == p.P && ln_fold_mode() == 1 && !W.w8) {
       g.stats_out = (float*)(ws + p.stats);
       if (wfl_gemm_stream_takes(g)) { stats_for = C; stats_nsl = W.N / 256; }
       else g.stats_out = nullptr;
@@ -1190,8 +1198,10 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       const EncLayer& L_ = m->enc[i];
       R.ln_gemm(X, Y, L_.ln1, L_.qkv, L_.qkv_ln, (int)Mrows, QK, 3 * d, WFL_ACT_NONE);
       R.attn(a.enc_heads);
+      R.next_stats = true;                                            // (consumed by the folded fc1)
       R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
       R.ln_gemm(X, Y, L_.ln2, L_.fc1, L_.fc1_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
+      R.next_stats = i + 1 < a.enc_layers;                            // (the next layer's folded q|k|v; the final LayerNorm is a kernel)
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
     }
     R.ln(X, Y, m->enc_ln, true);   // encoder output in Y (with lang_id None it is the head's residual stream)
@@ -1273,9 +1283,9 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       R.attn(a.enc_heads, rtab, gate);
       if (stable) {
         // x = x + attn; x = x + FFN(LN(x))
+        R.next_stats = L_.fc1_ln.ln_s != nullptr;
         R.gemm(ATT + (long)p.lead * d, d, L_.out, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
-        R.ln(H, S, L_.ln2);
-        R.gemm(S + (long)p.lead * d, d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+        R.ln_gemm(H, S, L_.ln2, L_.fc1, L_.fc1_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
         R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
       } else {
         // x = LN(x + attn); x = LN_final(x + FFN(x))
@@ -1372,9 +1382,11 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
       // dense k-tap conv: taps are adjacent rows (cin = d, tap stride = one row) -> the streaming GEMM's tap-stationary mode
       R.gemm(ATT + (long)(p.lead - a.conformer_kernel / 2) * d, d, C.conv, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU,
              nullptr, 0, 1.f, d, d);
+      R.next_stats = true;                                            // (consumed by the folded ff2)
       R.gemm(S + (long)p.lead * d, d, C.pw2, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
       // x = x + 0.5 * FF2(x)
       R.ln_gemm(H, S, C.ff2_ln, C.ff2_a, C.ff2_a_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
+      R.next_stats = i + 1 < a.n_conformer;                           // (the next block's folded ff1)
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff2_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
     }
     if (a.enable_dilated) {
