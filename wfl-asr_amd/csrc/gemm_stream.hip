@@ -39,6 +39,8 @@
                        // it the place the LDS-DMA instructions are issued from (WFL_DMA_IN_C = 1, 2: same time).  What is left is the
                        // issue cost of the 28 one-KiB LDS-DMA instructions themselves: the per-CU L2 -> LDS ceiling.
 
+#define SNCU 256
+
 typedef __attribute__((address_space(1))) const void* sgptr_t;
 typedef __attribute__((address_space(3))) void* slptr_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
