@@ -33,9 +33,13 @@ def _segments(ids, offsets, labels):
     return pp.merge_adjacent_segments(pp.decode_bio_tags(tags, offsets=offsets), "right")
 
 
-@pytest.mark.parametrize("target", ["fp32_weights", "bf16_weights"])
-def test_held_out_set_tag_index_parity(target, tmp_path):
-    cfg = synth.baseline_config(1)
+@pytest.mark.parametrize("target,head,n_clips", [("fp32_weights", "cfg2", N_CLIPS), ("bf16_weights", "cfg2", N_CLIPS),
+                                                 ("bf16_weights", "default_head", 8)])
+def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
+    """head = cfg2: BASELINE configs[1] (Whisper-base + 2 Conformer), all 64 clips.  head = default_head: the reference's default
+    config.yaml head (2-layer BiLSTM + 2 Conformer + 2 dilated convs) on the first 8 clips of the same set -- the oracle's BiLSTM is
+    a Python time loop, 8 clips keep it under a minute."""
+    cfg = synth.baseline_config(1) if head == "cfg2" else synth.base_config("whisper")
     cfg["output"]["save_dir"] = str(tmp_path)
     cfg["postprocess"] = {"median_filter": 1, "merge_segments": "right", "confidence_threshold": THR}
     labels = synth.make_labels(70)
@@ -46,7 +50,7 @@ def test_held_out_set_tag_index_parity(target, tmp_path):
         sd_np = synth.round_weights_bf16(sd_np)
     tau, band = (TAU_W, BAND_W) if target == "bf16_weights" else (TAU, BAND)
     # mixed lengths 1-30 s (a few exactly 30 s, a few very short), peak-normalised like infer.py:235 by the generator
-    u = synth.uniform01("heldout.len", N_CLIPS, SEED)
+    u = synth.uniform01("heldout.len", N_CLIPS, SEED)[:n_clips]
     secs = np.where(u < 0.1, 30.0, np.where(u > 0.9, 1.0 + 2.0 * u, 1.0 + 29.0 * u))
     clips = [synth.make_clip(CLIP0 + i, int(round(float(s) * 16000)), seed=SEED) for i, s in enumerate(secs)]
     lang_id = 1
@@ -79,12 +83,14 @@ def test_held_out_set_tag_index_parity(target, tmp_path):
             same_seq += 1
             for (s0, e0, _), (s1, e1, _) in zip(a, b):
                 shift = max(shift, abs(s0 - s1), abs(e0 - e1))
-    _note("heldout_" + target, clips=N_CLIPS, frames=frames, audio_s=float(secs.sum()), tau=tau, band=band,
+    _note("heldout_" + head + "_" + target, clips=n_clips, frames=frames, audio_s=float(secs.sum()), tau=tau, band=band,
           raw_mismatch_rate=raw_bad / frames, graded_frac=graded / frames, graded_mismatches=graded_bad, offsets_max=worst,
           clips_with_identical_label_sequence=same_seq, reference_segments=n_seg, max_boundary_shift_s=shift)
     assert graded_bad == 0
     assert worst <= 0.02
-    if target == "bf16_weights":
+    if head != "cfg2":
+        assert graded / frames >= 0.50 and raw_bad / frames < 0.04
+    elif target == "bf16_weights":
         assert graded / frames >= 0.75 and raw_bad / frames < 0.02
     else:
         assert graded / frames >= 0.58 and raw_bad / frames < 0.025
