@@ -345,7 +345,9 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
     case 32: return launch_attn<32, 2, true, false>(a, s);
     case 64: return launch_attn<64, 2, true, false>(a, s);
     case 128: return launch_attn<128, 2, true, false>(a, s);
-    case 256: return launch_attn<256, 1, false, false>(a, s);   // (QT = 2 with two tiles in LDS measured slower: 166 vs 124 us at cfg2 size)
+    // head_dim 256, measured at cfg2 size (tools/attn_bench.py): <256, 1, no prefetch> 125 us (two workgroups per CU hide each other's
+    // tile loads); <256, 2, prefetch> 166; <256, 2, no prefetch> 168; <256, 1, prefetch> 212 (one workgroup per CU each)
+    case 256: return launch_attn<256, 1, false, false>(a, s);
     // head_dim 384 (Whisper-small's Conformer heads): 32 queries per wave with Q in registers (506 VGPRs, one wave per SIMD) halves the
     // K / V tile traffic per query against attention_big's 16: 845 vs 2 635 us at 64 x 1500 frames (tools/attn_bench.py)
     case 384: return attn_variant() == 1 ? wfl_launch_attention_big(a, s) : launch_attn<384, 2, false, false>(a, s);
