@@ -97,6 +97,8 @@ struct LstmArgs {
   unsigned* error;                 // the forward's error word (ORed into)
   int grp0;                        // first clip group of this launch
   int ngroups;                     // clip groups of the whole batch (exchange indexing)
+  int ngroups_launch;              // clip groups of this launch
+  unsigned long long* roll;        // roll-call granules: [2 dir][groups][64]
 #ifdef WFL_LSTM_STAMPS
   unsigned long long* stamps;      // diagnostic build (tools/micro/lstm_bench.hip): [steps 64..95][8] phase stamps of WG (0,0,0) wave 0
 #endif
