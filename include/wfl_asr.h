@@ -26,6 +26,7 @@ typedef struct wfl_model wfl_model;
 
 #define WFL_ENC_WHISPER 0
 #define WFL_ENC_WAVLM 1
+#define WFL_ENC_NONE 2     /* no encoder: the hidden states are a power mel spectrogram (model.py:82-91, 149-150) */
 
 #define WFL_ABI_VERSION 2
 
@@ -69,7 +70,9 @@ typedef struct wfl_arch {
   int32_t wavlm_do_normalize;
   int32_t fp8_weights;               /* 1: the Whisper encoder layers' q|k|v, out_proj, fc1, fc2 weights are kept as OCP e4m3 with one
                                         fp32 scale per output channel (BASELINE configs[4]); 0: bf16 */
-  int32_t reserved[9];
+  int32_t mel_hop;                   /* WFL_ENC_NONE: hop of the mel front-end = int(frame_duration * sample_rate) (model.py:88);
+                                        d_model = n_mels = the hidden width (model.py:91); 160 and 320 are built */
+  int32_t reserved[8];
 } wfl_arch;
 
 const char* wfl_last_error(void);
@@ -96,7 +99,8 @@ int32_t wfl_device(const wfl_model* m);
  * 0 .. num_languages-1.  ids_host: n host int32, each in [0, num_languages). */
 int32_t wfl_set_average_languages(wfl_model* m, const int32_t* ids_host, int32_t n);
 
-/* Output frames for L input samples per clip (Whisper: always max_positions; WavLM: conv arithmetic). */
+/* Output frames for L input samples per clip (Whisper: always max_positions; WavLM: conv arithmetic; WFL_ENC_NONE:
+ * 1 + L / mel_hop, the centred STFT's frame count, 0 when L <= 200). */
 int32_t wfl_num_frames(const wfl_model* m, int32_t L);
 int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
 
@@ -114,7 +118,8 @@ int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
  *   maxprob    [B][T] fp32   max softmax probability
  *   offsets    [B][T][2] fp32 sigmoid sub-frame offsets
  *   logits     [B][T][C] fp32                                (optional)
- *   hidden     [B][T][d] fp32 encoder output                 (optional, parity tests)
+ *   hidden     [B][T][d] fp32 encoder output                 (optional, parity tests; WFL_ENC_NONE: the mel power, d = n_mels)
+ *   WavLM and WFL_ENC_NONE take clips of one length per call (lens must be null): the reference never pads their input.
  *   status     [1] int32 (device, optional): 0, or a bit mask of device-side errors of THIS forward (bit 0: an
  *              inter-workgroup wait of the BiLSTM recurrence timed out -- the tags are invalid).  Written by the last kernel
  *              of the forward, so it can ride in the same D2H copy as the tags.

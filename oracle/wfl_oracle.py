@@ -10,6 +10,10 @@ restatement is pinned against outputs of the reference itself, run in the build 
 the reference pins 4.51.3 — version caveat in SURVEY.md §8c) and committed as fixtures under
 `tests/golden/`; `tests/test_oracle_golden.py` checks every function here against them.
 
+Exception: `mel_spectrogram_power` (the `encoder_type: none` front-end) restates torchaudio.transforms.MelSpectrogram from its
+published definition -- torchaudio is not installed in this image and the reference holds no fixture for it, so that one function
+is PARITY UNPINNED (the head behind it is the same pinned `head_forward`).
+
 Every function cites the reference (or third-party) lines it follows:
   ref  = /root/reference/<file>
   HF   = transformers/<path> (5.15.0)
@@ -81,6 +85,37 @@ def whisper_log_mel(wav: torch.Tensor, n_mels: int = 80, n_samples: int = 480000
     mx = log_spec.amax(dim=(1, 2), keepdim=True)
     log_spec = torch.maximum(log_spec, mx - 8.0)
     return (log_spec + 4.0) / 4.0
+
+
+# ---------------------------------------------------------------------------------------
+# `encoder_type: none` front-end  ref model.py:82-91, 149-150 -> torchaudio.transforms.MelSpectrogram   (PARITY UNPINNED)
+# ---------------------------------------------------------------------------------------
+
+def mel_filter_bank_htk(n_mels: int, n_freq: int = 201, sr: int = 16000) -> np.ndarray:
+    """torchaudio.functional.melscale_fbanks(n_freq, 0.0, sr / 2, n_mels, sr, norm=None, mel_scale="htk") -> [n_freq, n_mels] f32.
+    m = 2595 log10(1 + f / 700); triangles of height 1 between consecutive mel-spaced points; computed in float32 like torchaudio."""
+    all_freqs = torch.linspace(0, sr // 2, n_freq)
+    m_min = 2595.0 * math.log10(1.0 + 0.0 / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + (sr / 2.0) / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.minimum(down, up), min=0.0).numpy()
+
+
+def mel_spectrogram_power(wav: torch.Tensor, sr: int = 16000, n_fft: int = 400, hop: int = 320, n_mels: int = 80) -> torch.Tensor:
+    """[B, L] f32 -> [B, n_mels, 1 + L // hop] f32: MelSpectrogram(sample_rate, n_fft, hop_length, n_mels) with torchaudio's defaults
+    (win_length = n_fft, periodic Hann, center=True, pad_mode="reflect", power=2, normalized=False, f_min=0, f_max=sr/2, HTK mel
+    scale, no filter normalisation, no log)."""
+    wav = wav.to(torch.float32)
+    spec = torch.stft(wav, n_fft, hop, n_fft, window=torch.hann_window(n_fft), center=True, pad_mode="reflect", normalized=False,
+                      onesided=True, return_complex=True)
+    power = spec.abs() ** 2
+    fb = torch.from_numpy(mel_filter_bank_htk(n_mels, 1 + n_fft // 2, sr))
+    return (power.transpose(-1, -2) @ fb).transpose(-1, -2)
 
 
 # ---------------------------------------------------------------------------------------
@@ -335,12 +370,14 @@ def to_torch_state_dict(sd_np: dict) -> dict:
 
 @torch.no_grad()
 def forward(wav: torch.Tensor, lang_id, sd: dict, enc: str, arch, hc: dict, return_hidden: bool = False):
-    """ref model.py:148-194 BIOPhonemeTagger.forward (encoder_type whisper | wavlm)."""
+    """ref model.py:148-194 BIOPhonemeTagger.forward (encoder_type whisper | wavlm | none)."""
     if enc == "whisper":
         feats = whisper_log_mel(wav, arch.n_mels, arch.max_positions * 2 * arch.hop, arch.n_fft, arch.hop)
         hidden = whisper_encoder(feats, sd, arch.heads, arch.layers)
     elif enc == "wavlm":
         hidden = wavlm_encoder(wavlm_normalize(wav.to(torch.float32), arch.do_normalize), sd, arch)
+    elif enc == "none":
+        hidden = mel_spectrogram_power(wav, arch.sample_rate, arch.n_fft, arch.hop, arch.n_mels).transpose(1, 2)
     else:
         raise ValueError(enc)
     logits, offsets = head_forward(hidden, lang_id, sd, hc)

@@ -45,6 +45,19 @@ class WavLMArch:
     layer_norm_eps: float = 1e-5
 
 
+@dataclass
+class MelArch:
+    """`encoder_type: none` (/root/reference/model.py:82-91): the hidden states are a torchaudio MelSpectrogram, width n_mels."""
+    d_model: int                 # = n_mels (model.py:91)
+    n_mels: int = 80
+    hop: int = 320               # int(frame_duration * sample_rate) (model.py:88)
+    n_fft: int = 400
+    sample_rate: int = 16000
+    layers: int = 0
+    heads: int = 1
+    ffn: int = 0
+
+
 WHISPER = {
     "tiny": WhisperArch(384, 4, 6, 1536),
     "base": WhisperArch(512, 6, 8, 2048),
@@ -74,11 +87,11 @@ def _suffix(name: str, prefix: str) -> str:
     return base.lstrip("-_")
 
 
-def resolve_encoder_arch(model_cfg: dict):
-    """config["model"] -> ("whisper", WhisperArch) | ("wavlm", WavLMArch).
+def resolve_encoder_arch(model_cfg: dict, data_cfg: dict | None = None):
+    """config["model"] (+ config["data"]) -> ("whisper", WhisperArch) | ("wavlm", WavLMArch) | ("none", MelArch).
 
-    Mirrors the selection at /root/reference/model.py:57-81; `encoder_type: none` (torchaudio
-    mel path, model.py:82-91) is out of scope and raises.
+    Mirrors the selection at /root/reference/model.py:57-93.  `encoder_type: none` reads sample_rate, frame_duration and n_mels
+    from config["data"] (model.py:85-90).
     """
     enc = str(model_cfg["encoder_type"]).lower()
     override = dict(model_cfg.get("encoder_arch") or {})
@@ -89,7 +102,16 @@ def resolve_encoder_arch(model_cfg: dict):
         key = _suffix(str(model_cfg["wavlm_model"]), "wavlm")
         table, cls = WAVLM, WavLMArch
     elif enc in ("none", "null"):
-        raise ValueError("encoder_type 'none' (torchaudio mel front-end) is outside the accelerated hot path")
+        if data_cfg is None:
+            raise ValueError("encoder_type 'none' needs config['data'] (sample_rate, frame_duration, n_mels)")
+        sr = int(data_cfg["sample_rate"])
+        if sr != 16000:
+            raise ValueError("encoder_type 'none': the mel front-end is built for 16 kHz input (config.data.sample_rate)")
+        n_mels = int(data_cfg.get("n_mels", 80))
+        arch = MelArch(n_mels, n_mels, int(data_cfg.get("frame_duration", 0.02) * sr), 400, sr)
+        if override:
+            raise ValueError("model.encoder_arch does not apply to encoder_type 'none'")
+        return "none", arch
     else:
         raise ValueError("Unsupported encoder type. Use 'whisper', 'wavlm', or 'none'.")
     if key in table:

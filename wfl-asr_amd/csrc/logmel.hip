@@ -12,17 +12,24 @@
 // (each bin feeds <= 2 triangles), log10, and an ordered-int atomic max per clip.
 // Kernel 2 applies the per-clip floor + affine and writes bf16 channels-last frame rows (the Whisper stem's
 // GEMM operand) and, for parity tests, an optional fp32 copy in the reference's [B, n_mels, frames] layout.
+//
+// The same STFT kernel, instantiated with POWER = true, is the `encoder_type: none` front-end (/root/reference/model.py:82-91,
+// 149-150: torchaudio.transforms.MelSpectrogram(sample_rate, n_fft=400, hop_length=frame_duration * sample_rate, n_mels), i.e.
+// periodic Hann, centred / reflect-padded frames, power 2, HTK mel triangles without normalisation, NO log): frames
+// 1 + L / hop, the plain mel power goes out as fp32 [B][frames][n_mels] (the hidden states themselves) and kernel 2' rounds it
+// into the head's bf16 frame rows.  Hop 160 and 320 are instantiated (frame_duration 0.01 / 0.02 s at 16 kHz).
 #include "common.h"
 
 #define NFFT 400
-#define HOP 160
 #define NBIN_PAD 224     // 201 bins padded to 7 MFMA column tiles
 #define FT 32            // frames per workgroup: 50 KB of LDS, so three workgroups share a CU and one's staging /
                          // mel phases run under the others' MFMA loops (64 frames = 100 KB = one per CU ran 2x slower)
 #define RT (FT / 32)     // 32-frame MFMA row tiles per workgroup
-#define SEG ((FT - 1) * HOP + NFFT)        // 5360 samples
-#define SEG_LDS (SEG + SEG / HOP + 2)      // skewed
 #define PPITCH 225
+template <int HOP> struct Seg {
+  static constexpr int SEG = (FT - 1) * HOP + NFFT;         // hop 160: 5360 samples
+  static constexpr int SEG_LDS = SEG + SEG / HOP + 2;       // skewed
+};
 #ifdef WFL_LOGMEL_STAMPS
 #define LSTAMP(k) do { if (threadIdx.x == 0 && p.stamps) p.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -51,7 +58,9 @@ static __device__ __forceinline__ float ord2f(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+template <int HOP, bool POWER>
 __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
+  constexpr int SEG = Seg<HOP>::SEG, SEG_LDS = Seg<HOP>::SEG_LDS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* seg = (float*)smem;
   float* pw = seg + ((SEG_LDS + 3) & ~3);
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { re[rt][e] = 0.f; im[rt][e] = 0.f; }
-    const float* fa = seg + 161 * r;                         // frame r of row tile 0 (skewed: + n + n/160); tile rt at + 161*32*rt
+    const float* fa = seg + (HOP + 1) * r;                   // frame r of row tile 0 (skewed: + n + n/HOP); tile rt at + (HOP+1)*32*rt
     const float* bc = p.Wc + (long)kh * NBIN_PAD + ct * 32 + r;   // row j-1 of the folded tables, j = 1 + 2*step + kh
     const float* bs = p.Ws + (long)kh * NBIN_PAD + ct * 32 + r;
     float wcv[PD], wsv[PD];
@@ -110,10 +119,10 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
     auto ldx = [&](int step, float (&xa)[RT], float (&xb)[RT]) __attribute__((always_inline)) {
       const int j = 1 + 2 * step + kh;                       // 1..200
       const int n2 = NFFT - j;                               // 200..399
-      const int a1 = j + (j >= 160 ? 1 : 0);
-      const int a2 = n2 + (n2 >= 320 ? 2 : 1);
+      const int a1 = j + (j >= HOP ? 1 : 0);                 // (j <= 200 < 2 HOP)
+      const int a2 = n2 + (n2 >= 2 * HOP ? 2 : (n2 >= HOP ? 1 : 0));
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) { xa[rt] = fa[161 * 32 * rt + a1]; xb[rt] = fa[161 * 32 * rt + a2]; }
+      for (int rt = 0; rt < RT; ++rt) { xa[rt] = fa[(HOP + 1) * 32 * rt + a1]; xb[rt] = fa[(HOP + 1) * 32 * rt + a2]; }
     };
     float na[RT], nb[RT];
     ldx(0, na, nb);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
     const float* mw = tab_lds ? lw + m * p.mel_maxw : p.mel_w + (long)m * p.mel_maxw;
     float acc = 0.f;
     for (int i = 0; i < cnt; ++i) acc += mw[i] * pw[f * PPITCH + lo + i];
-    const float lv = log10f(fmaxf(acc, 1e-10f));
+    const float lv = POWER ? acc : log10f(fmaxf(acc, 1e-10f));
     if (fvalid) {
       p.raw[((long)b * p.n_frames + f0 + f) * p.n_mels + m] = lv;
       mx = fmaxf(mx, lv);
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
-  if (lane == 0 && mx > -INFINITY) atomicMax(p.clipmax + b, f2ord(mx));
+  if (!POWER && lane == 0 && mx > -INFINITY) atomicMax(p.clipmax + b, f2ord(mx));
   LSTAMP(4);
 }
 
@@ -200,16 +209,53 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restr
   }
 }
 
-int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s) {
-  if (a.n_frames * HOP != a.n_samples || a.n_mels <= 0 || a.B <= 0) return -1;
-  constexpr int lds = (((SEG_LDS + 3) & ~3) + FT * PPITCH) * 4;
+// `none` front-end: raw [B][frames][n_mels] fp32 -> bf16 frame rows; channel m lands in column m + (m >= split ? shift : 0)
+// (the head's padded channel layout: model.hip, pad_head_state), the other columns of a row are left as they are (zero).
+__global__ __launch_bounds__(256) void melpower_rows_kernel(const float* __restrict__ raw, int B, int n_frames, int n_mels,
+                                                            bf16_t* __restrict__ out, long ldo, long lead, int P, int split, int shift) {
+  const long total = (long)B * n_frames * n_mels;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i % n_mels);
+    const long bf = i / n_mels;
+    const int t = (int)(bf % n_frames), b = (int)(bf / n_frames);
+    out[(lead + (long)b * P + t) * ldo + m + (m >= split ? shift : 0)] = f2bf(raw[i]);
+  }
+}
+
+template <int HOP, bool POWER>
+static int launch_power(const LogmelArgs& a, hipStream_t s) {
+  constexpr int lds = (((Seg<HOP>::SEG_LDS + 3) & ~3) + FT * PPITCH) * 4;
+  auto k = logmel_power_kernel<HOP, POWER>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
-    if (hipFuncSetAttribute((const void*)logmel_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
-  if (wfl_launch_fill_i32((int*)a.clipmax, a.B, 0, s)) return -3;          // (a kernel, not a memset node: common.h)
   dim3 grid((a.n_frames + FT - 1) / FT, a.B);
-  hipLaunchKernelGGL(logmel_power_kernel, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  return 0;
+}
+
+// encoder_type none: a.raw receives the mel power (= the hidden states, fp32 [B][frames][n_mels]); a.lens must be null (clips of
+// one length per call, reflected about their own last sample like a clip labelled alone), a.n_samples = a.L > 200.
+int wfl_launch_melpower(const LogmelArgs& a, int hop, bf16_t* out, long ldo, long lead, int P, int split, int shift, hipStream_t s) {
+  if (a.n_samples != a.L || a.L <= NFFT / 2 || a.n_frames != 1 + a.L / hop || a.n_mels <= 0 || a.B <= 0 || a.lens) return -1;
+  int r;
+  if (hop == 160) r = launch_power<160, true>(a, s);
+  else if (hop == 320) r = launch_power<320, true>(a, s);
+  else return -1;
+  if (r) return r;
+  const long total = (long)a.B * a.n_frames * a.n_mels;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(melpower_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.raw, a.B, a.n_frames, a.n_mels, out, ldo, lead,
+                     P, split, shift);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s) {
+  if (a.n_frames * 160 != a.n_samples || a.n_mels <= 0 || a.B <= 0) return -1;
+  if (wfl_launch_fill_i32((int*)a.clipmax, a.B, 0, s)) return -3;          // (a kernel, not a memset node: common.h)
+  if (int r = launch_power<160, false>(a, s)) return r;
   const long total = (long)a.B * a.n_frames * a.n_mels;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;

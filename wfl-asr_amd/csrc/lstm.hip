@@ -363,6 +363,9 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
     int r;
     switch (a.H) {
       case 32: r = launch_lstm_t<32, 2>(a, n, s); break;
+      case 64: r = launch_lstm_t<64, 2>(a, n, s); break;       // (encoder_type none: 80 mel bins in 128 columns)
+      case 128: r = launch_lstm_t<128, 2>(a, n, s); break;
+      case 192: r = launch_lstm_t<192, 2>(a, n, s); break;     // (Whisper-tiny)
       case 256: r = launch_lstm_t<256, 2>(a, n, s); break;
       case 384: r = launch_lstm_t<384, 2>(a, n, s); break;
       case 512: r = launch_lstm_t<512, 2>(a, n, s); break;

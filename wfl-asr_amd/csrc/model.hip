@@ -27,6 +27,7 @@ struct LogmelArgs {
   unsigned* clipmax;
 };
 int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s);
+int wfl_launch_melpower(const LogmelArgs& a, int hop, bf16_t* out, long ldo, long lead, int P, int split, int shift, hipStream_t s);
 
 struct TagArgs {
   const float* logits; long ldl;
@@ -43,7 +44,8 @@ struct TagArgs {
   int* status_dst;
 };
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
-int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s);
+int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s, int split,
+                           int shift);
 
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s);
 
@@ -65,7 +67,8 @@ int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, i
                            const float* b8, const float* cst, float* gate, hipStream_t s);
 int wfl_launch_relpos_table(const float* rel_emb, const int* bucket_of_delta, int max_t, int heads, int T, float* table, hipStream_t s);
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
-                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo = nullptr, bf16_t* y_lo = nullptr);
+                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo = nullptr, bf16_t* y_lo = nullptr,
+                             int n_div = 0);
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
@@ -80,7 +83,8 @@ struct ZeroMulti {
   unsigned* err_word;   // the forward's device-side error word, cleared here (first kernel of every forward); may be null
 };
 int wfl_launch_zero_halo_multi(const ZeroMulti& z, hipStream_t s);
-int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s);
+int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s, int split,
+                           int shift);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -145,6 +149,13 @@ struct wfl_model {
   std::vector<void*> dev_allocs;
   // geometry
   int halo = 16;
+  // `encoder_type: none` (WFL_ENC_NONE): the hidden width dv = n_mels (80) is no multiple of the 64 columns / supported head sizes
+  // the kernels are built for, so every d-wide tensor of the head lives in d >= dv columns (a.d_model is rewritten to d at
+  // wfl_create), valid channel c in column c + (c >= dv/2 ? d/2 - dv/2 : 0) -- the two halves a BiLSTM writes -- and zeros elsewhere;
+  // pad_head_state() moves the checkpoint's tensors into that layout, LayerNorm divides by dv.  dv == d for every other model.
+  int dv = 0;
+  int pad_split() const { return dv == a.d_model ? a.d_model : dv / 2; }
+  int pad_shift() const { return dv == a.d_model ? 0 : a.d_model / 2 - dv / 2; }
   // whisper front-end tables
   float *Wc = nullptr, *Ws = nullptr, *mel_w = nullptr;
   int *mel_lo = nullptr, *mel_cnt = nullptr;
@@ -189,9 +200,30 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (!arch || !out) return fail(-1, "wfl_create: null argument");
   if (arch->abi_version != WFL_ABI_VERSION) return fail(-1, "wfl_create: ABI version mismatch");
   const wfl_arch& a = *arch;
-  if (a.encoder_type != WFL_ENC_WHISPER && a.encoder_type != WFL_ENC_WAVLM) return fail(-1, "unknown encoder_type");
-  if (a.d_model <= 0 || a.d_model % 64) return fail(-1, "d_model must be a positive multiple of 64");
-  if (a.enc_heads <= 0 || a.d_model % a.enc_heads) return fail(-1, "enc_heads must divide d_model");
+  if (a.encoder_type != WFL_ENC_WHISPER && a.encoder_type != WFL_ENC_WAVLM && a.encoder_type != WFL_ENC_NONE)
+    return fail(-1, "unknown encoder_type");
+  const bool none = a.encoder_type == WFL_ENC_NONE;
+  int d_pad = a.d_model;
+  if (none) {
+    // model.py:82-91: hidden_size = n_mels; the head runs at that width
+    if (a.n_mels <= 0 || a.d_model != a.n_mels) return fail(-1, "encoder_type none: d_model must equal n_mels");
+    if (a.mel_hop != 160 && a.mel_hop != 320) return fail(-1, "encoder_type none: the mel front-end is built for hop 160 and 320 (frame_duration 0.01 / 0.02 s at 16 kHz)");
+    if (a.d_model % 2 && a.enable_bilstm) return fail(-1, "encoder_type none: odd n_mels with a BiLSTM");
+    if (a.n_conformer > 0) {
+      if (a.conformer_heads <= 0 || a.d_model % a.conformer_heads) return fail(-1, "bad conformer_heads");
+      d_pad = 0;
+      for (int hd : {32, 64, 128, 256}) {
+        const int dp = hd * a.conformer_heads;
+        if (hd >= a.d_model / a.conformer_heads && dp % 64 == 0) { d_pad = dp; break; }
+      }
+      if (!d_pad) return fail(-1, "encoder_type none: n_mels / conformer_heads above 256 is not supported");
+    } else {
+      d_pad = (int)round_up(a.d_model, 64);
+    }
+  } else {
+    if (a.d_model <= 0 || a.d_model % 64) return fail(-1, "d_model must be a positive multiple of 64");
+    if (a.enc_heads <= 0 || a.d_model % a.enc_heads) return fail(-1, "enc_heads must divide d_model");
+  }
   if (a.num_classes <= 0 || a.o_id < 0 || a.o_id >= a.num_classes) return fail(-1, "bad num_classes / o_id");
   if (a.n_conformer > 0 && (a.conformer_heads <= 0 || a.d_model % a.conformer_heads)) return fail(-1, "bad conformer_heads");
   if (a.n_conformer > 0 && a.conformer_kernel % 2 == 0) return fail(-1, "even conformer_kernel_size is not supported");
@@ -200,6 +232,8 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
     return fail(-1, "fp8_weights: Whisper encoders with d_model and ffn multiples of 256 only");
   wfl_model* m = new wfl_model();
   m->a = a;
+  m->dv = a.d_model;
+  m->a.d_model = d_pad;
   int pad = 1;
   if (a.n_conformer > 0) pad = std::max(pad, a.conformer_kernel / 2);
   if (a.enable_dilated)
@@ -429,20 +463,30 @@ struct Packer {
 
 // Slaney mel filter bank, as HF audio_utils.py:638-729 with feature_extraction_whisper.py:97-105's arguments
 // (0..8000 Hz, 201 bins, norm="slaney", mel_scale="slaney"); float64 then rounded to fp32 like the reference.
-static void build_mel(int n_mels, std::vector<int>& lo, std::vector<int>& cnt, std::vector<float>& w, int& maxw) {
+// htk = true: torchaudio.functional.melscale_fbanks(n_freqs = 201, 0, sr / 2, n_mels, sr, norm = None, mel_scale = "htk"), the bank
+// behind torchaudio.transforms.MelSpectrogram's defaults (/root/reference/model.py:85-90): m = 2595 log10(1 + f / 700), plain
+// triangles of height 1.
+static void build_mel(int n_mels, std::vector<int>& lo, std::vector<int>& cnt, std::vector<float>& w, int& maxw, bool htk = false,
+                      double fmax = 8000.0) {
   const int nf = 201;
-  auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4)) : 3.0 * f / 200.0; };
-  auto mel2hz = [](double mm) { return mm >= 15.0 ? 1000.0 * std::exp((std::log(6.4) / 27.0) * (mm - 15.0)) : 200.0 * mm / 3.0; };
-  const double m0 = hz2mel(0.0), m1 = hz2mel(8000.0);
+  auto hz2mel = [htk](double f) {
+    if (htk) return 2595.0 * std::log10(1.0 + f / 700.0);
+    return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4)) : 3.0 * f / 200.0;
+  };
+  auto mel2hz = [htk](double mm) {
+    if (htk) return 700.0 * (std::pow(10.0, mm / 2595.0) - 1.0);
+    return mm >= 15.0 ? 1000.0 * std::exp((std::log(6.4) / 27.0) * (mm - 15.0)) : 200.0 * mm / 3.0;
+  };
+  const double m0 = hz2mel(0.0), m1 = hz2mel(fmax);
   std::vector<double> ff(n_mels + 2);
   for (int i = 0; i < n_mels + 2; ++i) ff[i] = mel2hz(m0 + (m1 - m0) * i / (n_mels + 1));
   std::vector<std::vector<float>> fb(n_mels, std::vector<float>(nf, 0.f));
   for (int k = 0; k < nf; ++k) {
-    const double f = 8000.0 * k / (nf - 1);
+    const double f = fmax * k / (nf - 1);
     for (int i = 0; i < n_mels; ++i) {
       const double down = (f - ff[i]) / (ff[i + 1] - ff[i]);
       const double up = (ff[i + 2] - f) / (ff[i + 2] - ff[i + 1]);
-      const double v = std::max(0.0, std::min(down, up)) * (2.0 / (ff[i + 2] - ff[i]));
+      const double v = std::max(0.0, std::min(down, up)) * (htk ? 1.0 : 2.0 / (ff[i + 2] - ff[i]));
       fb[i][k] = (float)v;
     }
   }
@@ -463,32 +507,151 @@ static void build_mel(int n_mels, std::vector<int>& lo, std::vector<int>& cnt, s
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ finalize
+// STFT front-end tables: Hann-folded DFT matrix (periodic Hann as torch.hann_window(400)) + the sparse mel bank
+static void build_frontend_tables(wfl_model* m, Packer& P, bool htk, double fmax) {
+  // folded about n = 200 (see logmel.hip): row j-1 <-> sample j = 1..200; Wc[200] carries the factor 1/2
+  std::vector<float> wc((size_t)200 * 224, 0.f), ws((size_t)200 * 224, 0.f);
+  for (int j = 1; j <= 200; ++j) {
+    const double hann = 0.5 - 0.5 * std::cos(2.0 * M_PI * j / 400.0);
+    const double fold = j == 200 ? 0.5 : 1.0;
+    for (int k = 0; k <= 200; ++k) {
+      const int nk = (int)(((long)j * k) % 400);
+      const double ang = 2.0 * M_PI * nk / 400.0;
+      wc[(size_t)(j - 1) * 224 + k] = (float)(fold * hann * std::cos(ang));
+      ws[(size_t)(j - 1) * 224 + k] = (float)(-hann * std::sin(ang));
+    }
+  }
+  m->Wc = P.upload(wc);
+  m->Ws = P.upload(ws);
+  std::vector<int> lo, cnt;
+  std::vector<float> w;
+  build_mel(m->a.n_mels, lo, cnt, w, m->mel_maxw, htk, fmax);
+  m->mel_lo = P.upload(lo);
+  m->mel_cnt = P.upload(cnt);
+  m->mel_w = P.upload(w);
+}
+
+// `encoder_type: none`: move the head's checkpoint tensors (width dv) into the padded channel layout (width d, see wfl_model::dv).
+// Rows / columns that carry no channel are zero, so every padded activation column stays exactly zero through Linear, Conv1d,
+// GELU / ReLU / GLU, LayerNorm (gamma = beta = 0), eval-mode BatchNorm (scale 0), attention (zero q, k, v columns) and the LSTM
+// (zero gates: i = f = o = 1/2, g = 0, so c = h = 0).
+static void pad_head_state(wfl_model* m, Packer& P) {
+  const wfl_arch& a = m->a;
+  const int dv = m->dv, d = a.d_model, e = a.lang_emb_dim;
+  if (dv == d) return;
+  const int split = m->pad_split(), shift = m->pad_shift();
+  auto pi = [&](int c) { return c + (c >= split ? shift : 0); };
+  std::vector<int> PI(dv), ID_C(a.num_classes), ID2(2);
+  for (int c = 0; c < dv; ++c) PI[c] = pi(c);
+  for (int c = 0; c < a.num_classes; ++c) ID_C[c] = c;
+  ID2[0] = 0; ID2[1] = 1;
+  auto ident = [](int n) { std::vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = i; return v; };
+  // tensor [rows][cols][taps] (taps = 1: a matrix; cols = 0: a vector) -> [n_out][k_out][taps]
+  auto move = [&](const std::string& name, const std::vector<int>& rmap, int n_out, const std::vector<int>& cmap, int k_out, int taps,
+                  float fill = 0.f) {
+    auto it = m->host.find(name);
+    if (it == m->host.end()) return;                  // finalize_head reports the missing key
+    HostTensor& t = it->second;
+    std::vector<int64_t> want{(int64_t)rmap.size()};
+    if (!cmap.empty()) want.push_back((int64_t)cmap.size());
+    if (taps > 1 || t.shape.size() == 3) want.push_back(taps);
+    if (t.shape != want) {
+      if (P.err.empty()) {
+        P.err = "size mismatch for " + name + ": got [";
+        for (auto v : t.shape) P.err += std::to_string(v) + ",";
+        P.err += "] expected [";
+        for (auto v : want) P.err += std::to_string(v) + ",";
+        P.err += "]";
+      }
+      return;
+    }
+    HostTensor o;
+    const int kin = cmap.empty() ? 1 : (int)cmap.size(), kout = cmap.empty() ? 1 : k_out;
+    o.data.assign((size_t)n_out * kout * taps, fill);
+    for (size_t r = 0; r < rmap.size(); ++r)
+      for (int c = 0; c < kin; ++c)
+        for (int j = 0; j < taps; ++j)
+          o.data[((size_t)rmap[r] * kout + (cmap.empty() ? 0 : cmap[c])) * taps + j] = t.data[((size_t)r * kin + c) * taps + j];
+    o.shape.push_back(n_out);
+    if (!cmap.empty()) o.shape.push_back(k_out);
+    if (t.shape.size() == 3) o.shape.push_back(taps);
+    t = std::move(o);
+  };
+  const std::vector<int> none;
+  {                                                   // lang_proj: [dv][dv + e]: hidden columns through pi, embedding columns behind them
+    std::vector<int> cm(dv + e);
+    for (int c = 0; c < dv; ++c) cm[c] = pi(c);
+    for (int c = 0; c < e; ++c) cm[dv + c] = d + c;
+    move("lang_proj.weight", PI, d, cm, d + e, 1);
+    move("lang_proj.bias", PI, d, none, 0, 1);
+  }
+  if (a.enable_bilstm) {
+    const int Hv = dv / 2, Hp = d / 2;
+    std::vector<int> gm(4 * Hv);
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < Hv; ++u) gm[g * Hv + u] = g * Hp + u;
+    for (int layer = 0; layer < a.bilstm_layers; ++layer)
+      for (int dir = 0; dir < 2; ++dir) {
+        const std::string suf = "_l" + std::to_string(layer) + (dir ? "_reverse" : "");
+        move("bilstm.weight_ih" + suf, gm, 4 * Hp, PI, d, 1);          // layer 0 reads the hidden states, deeper ones [fwd | bwd]: both pi
+        move("bilstm.weight_hh" + suf, gm, 4 * Hp, ident(Hv), Hp, 1);
+        move("bilstm.bias_ih" + suf, gm, 4 * Hp, none, 0, 1);
+        move("bilstm.bias_hh" + suf, gm, 4 * Hp, none, 0, 1);
+      }
+  }
+  const int x = a.conformer_ff_expansion, kk = a.conformer_kernel;
+  for (int i = 0; i < a.n_conformer; ++i) {
+    const std::string p = "conformer_layers." + std::to_string(i) + ".";
+    const int hv = dv / a.conformer_heads, hp = d / a.conformer_heads;
+    std::vector<int> hm(dv), qm(3 * dv), gl(2 * dv);
+    for (int c = 0; c < dv; ++c) hm[c] = (c / hv) * hp + c % hv;             // per-head padding of the attention's channel axis
+    for (int b = 0; b < 3; ++b)
+      for (int c = 0; c < dv; ++c) qm[b * dv + c] = b * d + hm[c];
+    for (int c = 0; c < dv; ++c) { gl[c] = pi(c); gl[dv + c] = d + pi(c); }   // GLU: value half | gate half
+    for (const char* ff : {"ff1", "ff2"}) {
+      const std::string q = p + ff + ".net.";
+      move(q + "0.weight", PI, d, none, 0, 1);
+      move(q + "0.bias", PI, d, none, 0, 1);
+      move(q + "1.weight", ident(dv * x), d * x, PI, d, 1);
+      move(q + "1.bias", ident(dv * x), d * x, none, 0, 1);
+      move(q + "4.weight", PI, d, ident(dv * x), d * x, 1);
+      move(q + "4.bias", PI, d, none, 0, 1);
+    }
+    move(p + "self_attn.in_proj_weight", qm, 3 * d, PI, d, 1);
+    move(p + "self_attn.in_proj_bias", qm, 3 * d, none, 0, 1);
+    move(p + "self_attn.out_proj.weight", PI, d, hm, d, 1);
+    move(p + "self_attn.out_proj.bias", PI, d, none, 0, 1);
+    for (const char* ln : {"ln1", "ln2"}) {
+      move(p + ln + ".weight", PI, d, none, 0, 1);
+      move(p + ln + ".bias", PI, d, none, 0, 1);
+    }
+    move(p + "conv.0.weight", gl, 2 * d, PI, d, 1);
+    move(p + "conv.0.bias", gl, 2 * d, none, 0, 1);
+    move(p + "conv.2.weight", PI, d, PI, d, kk);
+    move(p + "conv.2.bias", PI, d, none, 0, 1);
+    move(p + "conv.3.weight", PI, d, none, 0, 1);
+    move(p + "conv.3.bias", PI, d, none, 0, 1);
+    move(p + "conv.3.running_mean", PI, d, none, 0, 1);
+    move(p + "conv.3.running_var", PI, d, none, 0, 1, 1.0f);
+    move(p + "conv.5.weight", PI, d, PI, d, 1);
+    move(p + "conv.5.bias", PI, d, none, 0, 1);
+  }
+  if (a.enable_dilated)
+    for (int i = 0; i < a.dilated_depth; ++i) {
+      const std::string p = "dilated_conv_stack." + std::to_string(2 * i);
+      move(p + ".weight", PI, d, PI, d, a.dilated_kernel);
+      move(p + ".bias", PI, d, none, 0, 1);
+    }
+  move("classifier.weight", ID_C, a.num_classes, PI, d, 1);
+  move("boundary_offset_head.0.weight", PI, d, PI, d, 3);
+  move("boundary_offset_head.0.bias", PI, d, none, 0, 1);
+  move("boundary_offset_head.2.weight", ID2, 2, PI, d, 1);
+}
+
 static int finalize_whisper(wfl_model* m, Packer& P) {
   const wfl_arch& a = m->a;
   const int d = a.d_model, hd = d / a.enc_heads;
-  // front-end tables: Hann-folded DFT matrix (periodic Hann as torch.hann_window(400))
-  {
-    // folded about n = 200 (see logmel.hip): row j-1 <-> sample j = 1..200; Wc[200] carries the factor 1/2
-    std::vector<float> wc((size_t)200 * 224, 0.f), ws((size_t)200 * 224, 0.f);
-    for (int j = 1; j <= 200; ++j) {
-      const double hann = 0.5 - 0.5 * std::cos(2.0 * M_PI * j / 400.0);
-      const double fold = j == 200 ? 0.5 : 1.0;
-      for (int k = 0; k <= 200; ++k) {
-        const int nk = (int)(((long)j * k) % 400);
-        const double ang = 2.0 * M_PI * nk / 400.0;
-        wc[(size_t)(j - 1) * 224 + k] = (float)(fold * hann * std::cos(ang));
-        ws[(size_t)(j - 1) * 224 + k] = (float)(-hann * std::sin(ang));
-      }
-    }
-    m->Wc = P.upload(wc);
-    m->Ws = P.upload(ws);
-    std::vector<int> lo, cnt;
-    std::vector<float> w;
-    build_mel(a.n_mels, lo, cnt, w, m->mel_maxw);
-    m->mel_lo = P.upload(lo);
-    m->mel_cnt = P.upload(cnt);
-    m->mel_w = P.upload(w);
-  }
+  build_frontend_tables(m, P, false, 8000.0);
   m->conv1 = P.conv("encoder.conv1", d, a.n_mels, 3);
   m->conv2 = P.conv("encoder.conv2", d, d, 3);
   if (const HostTensor* pe = P.get("encoder.embed_positions.weight", {a.max_positions, d})) {
@@ -717,7 +880,7 @@ static int finalize_head(wfl_model* m, Packer& P) {
     const HostTensor* iw = P.get(p + "self_attn.in_proj_weight", {3 * d, d});
     const HostTensor* ib = P.get(p + "self_attn.in_proj_bias", {3 * d});
     if (iw && ib) {
-      const int hd = d / a.conformer_heads;
+      const int hd = m->dv / a.conformer_heads;              // (the true head size; padded columns are zero)
       const float qs = (float)(std::pow((double)hd, -0.5) * 1.4426950408889634);
       std::vector<float> rows(iw->data), bias(ib->data);
       for (size_t j = 0; j < (size_t)d * d; ++j) rows[j] *= qs;
@@ -799,7 +962,11 @@ int32_t wfl_finalize(wfl_model* m) {
   Packer P{m};
   if (hipGetDevice(&m->device) != hipSuccess) return fail(-10, "wfl_finalize: hipGetDevice failed");
   if (m->a.encoder_type == WFL_ENC_WHISPER) finalize_whisper(m, P);
-  else finalize_wavlm(m, P);
+  else if (m->a.encoder_type == WFL_ENC_WAVLM) finalize_wavlm(m, P);
+  else {
+    build_frontend_tables(m, P, true, 8000.0);      // MelSpectrogram(f_min = 0, f_max = sample_rate / 2): 16 kHz input, like the rest of the path
+    pad_head_state(m, P);
+  }
   if (P.err.empty()) finalize_head(m, P);
   if (!P.err.empty()) return fail(-2, "wfl_finalize: " + P.err);
   for (auto& kv : m->host)
@@ -864,7 +1031,8 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   const bool whisper = a.encoder_type == WFL_ENC_WHISPER;
   Plan p{};
   p.B = B; p.L = L;
-  p.T = T_frames > 0 ? T_frames : (whisper ? a.max_positions : wavlm_frames(a, L));
+  const bool none = a.encoder_type == WFL_ENC_NONE;
+  p.T = T_frames > 0 ? T_frames : (whisper ? a.max_positions : (none ? 1 + L / a.mel_hop : wavlm_frames(a, L)));
   p.P = (int)round_up(p.T + m->halo, 8);
   p.lead = m->halo;
   p.tail = 256;
@@ -880,6 +1048,8 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
     p.mel = take(p.R2 * a.n_mels * 2 + 1024);
     p.c1 = take(p.R2 * p.d * 2);
     p.raw = take((long)B * p.T2 * a.n_mels * 4);
+  } else if (none) {
+    p.raw = take((long)B * p.T * a.n_mels * 4);        // the mel power = the hidden states, fp32 [B][T][n_mels]
   } else {
     const int n = a.wavlm_n_conv, C = a.wavlm_conv_dim[0];
     p.nlev = n;
@@ -929,6 +1099,7 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
 
 int32_t wfl_num_frames(const wfl_model* m, int32_t L) {
   if (!m) return -1;
+  if (m->a.encoder_type == WFL_ENC_NONE) return L > 200 ? 1 + L / m->a.mel_hop : 0;    // (reflect padding needs L > n_fft / 2)
   return m->a.encoder_type == WFL_ENC_WHISPER ? m->a.max_positions : wavlm_frames(m->a, L);
 }
 
@@ -1043,7 +1214,7 @@ struct Runner {
   void ln_gemm(const bf16_t* x, bf16_t* scratch, const LNp& w, const Lin& plain, const Lin& folded, int M, void* C, long ldc,
                int act) {
     if (rc) return;
-    const int mode = ln_fold_mode();
+    const int mode = m->dv != p.d ? 0 : ln_fold_mode();        // (the folded form divides by K: not for a zero-padded width)
     if (folded.ln_s && (mode == 2 || (mode == 1 && stats_for == x))) {
       GemmArgs g{};
       g.M = M; g.N = folded.N; g.K = folded.K; g.cin = folded.K; g.n_valid = folded.n_valid; g.act = act; g.ln_s = folded.ln_s;
@@ -1066,7 +1237,7 @@ struct Runner {
     bf16_t* y_lo = lo_out ? lo_of(y) : nullptr;
     { const int yi = lo_idx(y); if (yi >= 0) lo_ok[yi] = y_lo != nullptr; }
     prof_begin();
-    const int r = wfl_launch_layernorm_act(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, 0, s, x_lo, y_lo);
+    const int r = wfl_launch_layernorm_act(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, 0, s, x_lo, y_lo, m->dv);
     prof_end(2043, 0.0);
     if (r) rc = fail(r, "layernorm launch failed");
   }
@@ -1169,6 +1340,8 @@ static int begin_forward(Runner& R, bool with_encoder) {
     R.zero_add(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
   }
   R.zero_flush();
+  // a zero-padded width (encoder_type none): the front-end / wfl_head write only the valid columns of the Y rows
+  if (!R.rc && R.m->dv != d && wfl_launch_fill_i32((int*)(R.ws + p.Y), p.R * d / 2, 0, R.s)) return fail(-3, "fill launch failed");
   return R.rc;
 }
 
@@ -1205,6 +1378,21 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
     }
     R.ln(X, Y, m->enc_ln, true);   // encoder output in Y (with lang_id None it is the head's residual stream)
+  } else if (a.encoder_type == WFL_ENC_NONE) {
+    // ---- no encoder: hidden = MelSpectrogram(wav).transpose(1, 2) (model.py:149-150).  Like WavLM input it is never padded by the
+    // reference: one clip length per call.
+    if (lens) return fail(-1, "wfl_forward: per-clip lengths are not supported with encoder_type none (batch clips of equal length)");
+    if (L <= 200) return fail(-1, "wfl_forward: encoder_type none needs more than 200 samples (reflect padding of the STFT)");
+    LogmelArgs la{};
+    la.wav = wav; la.ldw = ldw; la.lens = nullptr; la.L = L; la.B = B;
+    la.n_frames = p.T; la.n_samples = L; la.n_mels = a.n_mels;
+    la.Wc = m->Wc; la.Ws = m->Ws; la.mel_lo = m->mel_lo; la.mel_cnt = m->mel_cnt; la.mel_w = m->mel_w; la.mel_maxw = m->mel_maxw;
+    la.raw = (float*)(R.ws + p.raw); la.clipmax = nullptr;
+    R.prof_begin();
+    const int r = wfl_launch_melpower(la, a.mel_hop, Y, d, p.lead, p.P, m->pad_split(), m->pad_shift(), R.s);
+    R.prof_end(2042, 0.0);
+    if (r) return fail(r, "mel launch failed");
+    R.lo_ok[1] = false;
   } else {
     // ---- WavLM (HF modeling_wavlm.py:1032-1088).  `lens` is not supported: the reference never pads WavLM input.
     if (lens) return fail(-1, "wfl_forward: per-clip lengths are not supported with the WavLM encoder (batch clips of equal length)");
@@ -1305,6 +1493,15 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     }
   }
   return R.rc;
+}
+
+// The encoder output as the caller sees it: compact fp32 [B][T][hidden_size]
+static int emit_hidden(Runner& R, float* hidden) {
+  const wfl_model* m = R.m;
+  const Plan& p = R.p;
+  if (m->a.encoder_type == WFL_ENC_NONE)           // the mel power itself, before its rounding into the bf16 rows
+    return wfl_launch_axpy(hidden, (const float*)(R.ws + p.raw), (long)p.B * p.T * m->a.n_mels, 1.f, 1, R.s);
+  return wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, p.B, p.P, p.T, m->dv, hidden, R.s, m->pad_split(), m->pad_shift());
 }
 
 // Head (model.py:176-194) + tag decision on the encoder output in the Y rows.
@@ -1476,7 +1673,7 @@ int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* 
   if (int r = begin_forward(R, true)) return r;
   if (int r = run_encoder(R, wav, ldw, lens)) return r;
   if (hidden) {
-    const int r = wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, B, p.P, p.T, p.d, hidden, R.s);
+    const int r = emit_hidden(R, hidden);
     if (r) return fail(r, "rows_to_f32 launch failed");
   }
   return run_head(R, lang_id, lang_mode, threshold, ids, argmax, maxprob, offsets, logits, status);
@@ -1493,7 +1690,7 @@ int32_t wfl_encode(wfl_model* m, const float* wav, int64_t ldw, const int32_t* l
   if (p.T <= 0) return fail(-1, "wfl_encode: clip too short for the encoder");
   if (int r = begin_forward(R, true)) return r;
   if (int r = run_encoder(R, wav, ldw, lens)) return r;
-  const int r = wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, B, p.P, p.T, p.d, hidden, R.s);
+  const int r = emit_hidden(R, hidden);
   return r ? fail(r, "rows_to_f32 launch failed") : 0;
 }
 
@@ -1513,7 +1710,7 @@ int32_t wfl_head(wfl_model* m, const float* hidden, int32_t B, int32_t T, const 
   const Plan& p = R.p;
   if (!workspace || workspace_bytes < p.total) return fail(-1, "wfl_head: workspace too small");
   if (int r = begin_forward(R, false)) return r;
-  const int r = wfl_launch_f32_to_rows(hidden, R.buf(p.Y), p.d, p.lead, B, p.P, p.T, p.d, R.s);
+  const int r = wfl_launch_f32_to_rows(hidden, R.buf(p.Y), p.d, p.lead, B, p.P, p.T, m->dv, R.s, m->pad_split(), m->pad_shift());
   if (r) return fail(r, "f32_to_rows launch failed");
   return run_head(R, lang_id, lang_mode, threshold, ids, argmax, maxprob, offsets, logits, status);
 }

@@ -9,8 +9,11 @@ template <int NCH, bool GELU>   // 16-byte chunks per lane (C <= NCH * 512); GEL
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                         long ldy, const float* __restrict__ gam,
                                                         const float* __restrict__ bet, float eps, long lead, int B, int P,
-                                                        int T, int C, const bf16_t* __restrict__ x_lo, bf16_t* __restrict__ y_lo) {
+                                                        int T, int C, const bf16_t* __restrict__ x_lo, bf16_t* __restrict__ y_lo,
+                                                        int n_div) {
   // x_lo / y_lo: the low halves of a residual-stream tensor carried as hi + lo (common.h, GemmArgs::res_lo); both optional
+  // n_div: channels the statistics are taken over; < C when the row carries zero padding columns (gamma = beta = 0 there: the
+  //        `encoder_type: none` head, whose width 80 lives in 128 columns -- model.hip, pad_head_state)
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // index over B*T valid rows
   if (r >= (long)B * T) return;
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
-  const float mean = sum / (float)C;
+  const float mean = sum / (float)n_div;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
-  const float rstd = rsqrtf(sq / (float)C + eps);
+  if (n_div != C) sq -= (float)(C - n_div) * mean * mean;       // the padding columns' (0 - mean)^2
+  const float rstd = rsqrtf(fmaxf(sq, 0.f) / (float)n_div + eps);
   bf16_t* yp = y + row * ldy;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -78,28 +82,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 template <bool GELU>
 static int launch_ln(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead, int B,
-                     int P, int T, int C, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo) {
+                     int P, int T, int C, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo, int n_div) {
   const long rows = (long)B * T;
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (C <= 512)
-    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo);
+    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div);
   else if (C <= 1024)
-    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo);
+    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div);
   else
-    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo);
+    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
-                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo) {
-  if (C % 8 || ldx % 8 || ldy % 8 || C > 2048) return -1;
-  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo)
-              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo);
+                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo, int n_div) {
+  if (C % 8 || ldx % 8 || ldy % 8 || C > 2048 || n_div < 0 || n_div > C) return -1;
+  if (n_div == 0) n_div = C;
+  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo, n_div)
+              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo, n_div);
 }
 
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
                          long lead, int B, int P, int T, int C, hipStream_t s) {
-  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s, nullptr, nullptr);
+  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s, nullptr, nullptr, 0);
 }
 
 // Zero every row that is not a valid frame: [0, lead), each clip's [T, P), and `tail_rows` rows behind the last
@@ -136,42 +141,46 @@ int wfl_launch_zero_halo(bf16_t* buf, long ld_bytes, long lead, int B, int P, in
 }
 
 // bf16 frame rows -> compact fp32 [B][T][C] (parity-test output of the encoder's hidden states)
+// (split, shift): compact channel c lives in row column c + (c >= split ? shift : 0) -- the padded head layout of model.hip's
+// pad_head_state; split = C, shift = 0 for every other model
 __global__ __launch_bounds__(256) void rows_to_f32_kernel(const bf16_t* __restrict__ x, long ldx, long lead, int B, int P, int T,
-                                                          int C, float* __restrict__ out) {
+                                                          int C, float* __restrict__ out, int split, int shift) {
   const long total = (long)B * T * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long bt = i / C;
     const int t = (int)(bt % T), b = (int)(bt / T);
-    out[i] = bf2f(x[(lead + (long)b * P + t) * ldx + c]);
+    out[i] = bf2f(x[(lead + (long)b * P + t) * ldx + c + (c >= split ? shift : 0)]);
   }
 }
 
-int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s) {
+int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s, int split,
+                           int shift) {
   const long total = (long)B * T * C;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rows_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, C, out);
+  hipLaunchKernelGGL(rows_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, C, out, split, shift);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // compact fp32 [B][T][C] -> bf16 frame rows (wfl_head: the caller's encoder output)
 __global__ __launch_bounds__(256) void f32_to_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ x, long ldx, long lead,
-                                                          int B, int P, int T, int C) {
+                                                          int B, int P, int T, int C, int split, int shift) {
   const long total = (long)B * T * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long bt = i / C;
     const int t = (int)(bt % T), b = (int)(bt / T);
-    x[(lead + (long)b * P + t) * ldx + c] = f2bf(in[i]);
+    x[(lead + (long)b * P + t) * ldx + c + (c >= split ? shift : 0)] = f2bf(in[i]);
   }
 }
 
-int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s) {
+int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s, int split,
+                           int shift) {
   const long total = (long)B * T * C;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(f32_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, x, ldx, lead, B, P, T, C);
+  hipLaunchKernelGGL(f32_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, x, ldx, lead, B, P, T, C, split, shift);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

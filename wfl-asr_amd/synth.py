@@ -170,8 +170,8 @@ def head_spec(d: int, num_classes: int, h: dict, cls_gain: float = 6.0) -> Order
 
 
 def state_dict_spec(config: dict, num_classes: int, cls_gain: float = 6.0) -> OrderedDict:
-    enc, arch = resolve_encoder_arch(config["model"])
-    s = whisper_spec(arch) if enc == "whisper" else wavlm_spec(arch)
+    enc, arch = resolve_encoder_arch(config["model"], config.get("data"))
+    s = whisper_spec(arch) if enc == "whisper" else (wavlm_spec(arch) if enc == "wavlm" else OrderedDict())
     s.update(head_spec(arch.d_model, num_classes, head_config(config["model"]), cls_gain))
     return s
 

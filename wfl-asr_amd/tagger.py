@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .archs import WhisperArch, head_config, resolve_encoder_arch
+from .archs import MelArch, WhisperArch, head_config, resolve_encoder_arch
 
 LANG_NONE, LANG_IDS, LANG_AVERAGE = 0, 1, 2
 
@@ -54,7 +54,7 @@ class BIOPhonemeTagger:
         kernel launch of this object happens with that device current."""
         self.config = config
         self.device = _resolve_device(device) if device is not None else None
-        self.encoder_type, self.arch = resolve_encoder_arch(config["model"])
+        self.encoder_type, self.arch = resolve_encoder_arch(config["model"], config.get("data"))
         self.head_cfg = head_config(config["model"])
         self.label_list = list(label_list)
         self.label2id = {label: i for i, label in enumerate(self.label_list)}
@@ -71,9 +71,11 @@ class BIOPhonemeTagger:
         self._graphs = {}
         a = _lib.WflArch()
         a.abi_version = _lib.ABI_VERSION
-        a.encoder_type = 0 if self.encoder_type == "whisper" else 1
+        a.encoder_type = {"whisper": 0, "wavlm": 1, "none": 2}[self.encoder_type]
         a.d_model, a.enc_layers, a.enc_heads, a.enc_ffn = self.arch.d_model, self.arch.layers, self.arch.heads, self.arch.ffn
-        if isinstance(self.arch, WhisperArch):
+        if isinstance(self.arch, MelArch):
+            a.n_mels, a.mel_hop = self.arch.n_mels, self.arch.hop
+        elif isinstance(self.arch, WhisperArch):
             a.n_mels, a.max_positions = self.arch.n_mels, self.arch.max_positions
             a.fp8_weights = int(str(config["model"].get("weight_dtype", "bf16")).lower() in ("fp8", "e4m3", "float8_e4m3fn"))
             if (self.arch.n_fft, self.arch.hop) != (400, 160):
