@@ -227,6 +227,13 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (a.num_classes <= 0 || a.o_id < 0 || a.o_id >= a.num_classes) return fail(-1, "bad num_classes / o_id");
   if (a.n_conformer > 0 && (a.conformer_heads <= 0 || a.d_model % a.conformer_heads)) return fail(-1, "bad conformer_heads");
   if (a.n_conformer > 0 && a.conformer_kernel % 2 == 0) return fail(-1, "even conformer_kernel_size is not supported");
+  if (a.n_conformer > 0) {
+    const int hd = d_pad / a.conformer_heads;
+    bool ok = false;
+    for (int v : {32, 64, 128, 256, 384, 512, 640}) ok = ok || v == hd;
+    if (!ok)
+      return fail(-1, "conformer head size " + std::to_string(hd) + " (d_model / conformer_heads) is not built: 32, 64, 128, 256, 384, 512 or 640");
+  }
   if (a.enable_dilated && a.dilated_kernel % 2 == 0) return fail(-1, "even dilated_conv_kernel is not supported");
   if (a.fp8_weights && (a.encoder_type != WFL_ENC_WHISPER || a.d_model % 256 || a.enc_ffn % 256))
     return fail(-1, "fp8_weights: Whisper encoders with d_model and ffn multiples of 256 only");
