@@ -268,3 +268,30 @@ def test_wavlm_labeler_exact_length_buckets_pipelined(tmp_path):
     got = lab.label_files(paths, lang_id=0, confidence_threshold=0.3, verbose=False)
     for path, segs in zip(paths, got):
         assert segs == _manual(lab, path, 0, 0.3), path
+
+
+def test_whisper_tiny_default_head_runs_its_192_wide_heads_as_256():
+    """openai/whisper-tiny (d = 384) under the reference's default config.yaml head: conformer_heads 2 gives a head size of 192,
+    which no attention kernel is built for -- the q | k | v projection writes 256-wide heads with zero padding (QKp / ATTp), and the
+    BiLSTM runs at hidden size 192.  Held against the oracle's plain 192-wide heads."""
+    cfg = synth.base_config("whisper", whisper_model="openai/whisper-tiny")
+    m, labels, sd_np = _build(cfg, 30, seed=66)
+    wav = synth.make_batch(860, 2, 16000 * 11, seed=66)
+    lang = np.array([1, 0], np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.4, want_logits=True)
+    enc_name, arch = resolve_encoder_arch(cfg["model"])
+    assert arch.d_model == 384 and synth.head_config(cfg["model"])["conformer_heads"] == 2
+    lg, of = O.forward(torch.from_numpy(wav), torch.from_numpy(lang), O.to_torch_state_dict(sd_np), enc_name, arch,
+                       synth.head_config(cfg["model"]))
+    ids, maxp, arg, margin = O.tags_from_logits(lg, m.label2id["O"], 0.4)
+    err = (out.logits.cpu() - lg).abs()
+    scale = float(lg.std())
+    print("whisper-tiny default head: err max %.3f mean %.4f std %.2f" % (err.max(), err.mean(), scale))
+    assert err.max() <= 0.07 * scale and err.mean() <= 0.011 * scale       # (measured 0.044 and 0.0069 of the logit std)
+    assert (out.offsets.cpu() - of).abs().max() <= 0.03
+    safe = (margin > 0.08 * scale) & ((maxp - 0.4).abs() > 0.06)
+    assert float(safe.float().mean()) > 0.5
+    assert torch.equal(out.ids.cpu()[safe].long(), ids[safe])
+    assert int(out.status.item()) == 0
+    one = m.label(torch.from_numpy(wav[:1]).cuda(), lang[:1], threshold=0.4, want_logits=True)
+    assert torch.equal(one.logits[0], out.logits[0])

@@ -154,6 +154,10 @@ struct wfl_model {
   // wfl_create), valid channel c in column c + (c >= dv/2 ? d/2 - dv/2 : 0) -- the two halves a BiLSTM writes -- and zeros elsewhere;
   // pad_head_state() moves the checkpoint's tensors into that layout, LayerNorm divides by dv.  dv == d for every other model.
   int dv = 0;
+  // Conformer attention: head size the attention kernels are built for (32 .. 640) at or above d / conformer_heads, and the width
+  // heads * that of its q | k | v and context rows.  Whisper-tiny's 192 (384 / 2 heads) runs as 256: the q | k | v projection writes
+  // zero columns behind every head (QKp / ATTp buffers of the plan), out_proj skips them.  Equal to d for every BASELINE config.
+  int conf_hd = 0, conf_da = 0;
   int pad_split() const { return dv == a.d_model ? a.d_model : dv / 2; }
   int pad_shift() const { return dv == a.d_model ? 0 : a.d_model / 2 - dv / 2; }
   // whisper front-end tables
@@ -227,12 +231,12 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (a.num_classes <= 0 || a.o_id < 0 || a.o_id >= a.num_classes) return fail(-1, "bad num_classes / o_id");
   if (a.n_conformer > 0 && (a.conformer_heads <= 0 || a.d_model % a.conformer_heads)) return fail(-1, "bad conformer_heads");
   if (a.n_conformer > 0 && a.conformer_kernel % 2 == 0) return fail(-1, "even conformer_kernel_size is not supported");
+  int conf_hd = 0;
   if (a.n_conformer > 0) {
     const int hd = d_pad / a.conformer_heads;
-    bool ok = false;
-    for (int v : {32, 64, 128, 256, 384, 512, 640}) ok = ok || v == hd;
-    if (!ok)
-      return fail(-1, "conformer head size " + std::to_string(hd) + " (d_model / conformer_heads) is not built: 32, 64, 128, 256, 384, 512 or 640");
+    for (int v : {32, 64, 128, 256, 384, 512, 640})
+      if (!conf_hd && v >= hd) conf_hd = v;
+    if (!conf_hd) return fail(-1, "conformer head size " + std::to_string(hd) + " (d_model / conformer_heads) is above 640");
   }
   if (a.enable_dilated && a.dilated_kernel % 2 == 0) return fail(-1, "even dilated_conv_kernel is not supported");
   if (a.fp8_weights && (a.encoder_type != WFL_ENC_WHISPER || a.d_model % 256 || a.enc_ffn % 256))
@@ -241,6 +245,8 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   m->a = a;
   m->dv = a.d_model;
   m->a.d_model = d_pad;
+  m->conf_hd = conf_hd;
+  m->conf_da = conf_hd * (a.n_conformer > 0 ? a.conformer_heads : 0);
   int pad = 1;
   if (a.n_conformer > 0) pad = std::max(pad, a.conformer_kernel / 2);
   if (a.enable_dilated)
@@ -892,9 +898,33 @@ static int finalize_head(wfl_model* m, Packer& P) {
       std::vector<float> rows(iw->data), bias(ib->data);
       for (size_t j = 0; j < (size_t)d * d; ++j) rows[j] *= qs;
       for (int j = 0; j < d; ++j) bias[j] *= qs;
-      C.qkv = P.pack(rows, 3 * d, d, &bias);
+      const int da = m->conf_da, hp = m->conf_hd, hv = d / a.conformer_heads;
+      if (da == d) {
+        C.qkv = P.pack(rows, 3 * d, d, &bias);
+      } else {                                               // head h's rows move to [h * hp, h * hp + hv) of each da-wide block
+        std::vector<float> prow((size_t)3 * da * d, 0.f), pbias((size_t)3 * da, 0.f);
+        for (int b3 = 0; b3 < 3; ++b3)
+          for (int c = 0; c < d; ++c) {
+            const size_t dst = (size_t)b3 * da + (c / hv) * hp + c % hv;
+            memcpy(&prow[dst * d], &rows[((size_t)b3 * d + c) * d], sizeof(float) * d);
+            pbias[dst] = bias[(size_t)b3 * d + c];
+          }
+        C.qkv = P.pack(prow, 3 * da, d, &pbias);
+      }
     }
-    C.out = P.linear(p + "self_attn.out_proj", d, d);
+    if (m->conf_da == d) {
+      C.out = P.linear(p + "self_attn.out_proj", d, d);
+    } else {
+      const HostTensor* ow = P.get(p + "self_attn.out_proj.weight", {d, d});
+      const HostTensor* ob = P.get(p + "self_attn.out_proj.bias", {d});
+      if (ow && ob) {
+        const int da = m->conf_da, hp = m->conf_hd, hv = d / a.conformer_heads;
+        std::vector<float> prow((size_t)d * da, 0.f);
+        for (int n = 0; n < d; ++n)
+          for (int c = 0; c < d; ++c) prow[(size_t)n * da + (c / hv) * hp + c % hv] = ow->data[(size_t)n * d + c];
+        C.out = P.pack(prow, d, da, &ob->data);
+      }
+    }
     C.ln1 = P.ln(p + "ln1", d);
     C.ln2 = P.ln(p + "ln2", d);
     // pointwise conv d -> 2d followed by GLU: interleave rows in groups of 16 (a | gate)
@@ -1020,7 +1050,8 @@ struct Plan {
   long Rl[8];
   // byte offsets
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
-  long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, total;
+  long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, QKp, ATTp, total;
+  int da;                       // Conformer attention width (wfl_model::conf_da); QKp / ATTp exist when it differs from d
 };
 
 static int wavlm_frames(const wfl_arch& a, int L) {
@@ -1086,6 +1117,11 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   p.ATT = take(p.R * p.d * 2);
   p.QK = take(p.R * 3 * p.d * 2);                   // packed q | k | v rows
   p.FF = take(p.R * p.ffw * 2);
+  p.da = m->conf_da > 0 ? m->conf_da : p.d;
+  if (p.da != p.d) {
+    p.QKp = take(p.R * 3 * p.da * 2);
+    p.ATTp = take(p.R * p.da * 2);
+  }
   p.stats = take(p.R * 4L * 2 * 4);                     // per row, per 256-column tile (<= 4): (sum, sum of squares)
   p.enc2 = take(p.R * p.d * 2);
   p.clipmax = take((long)B * 4);
@@ -1272,16 +1308,19 @@ struct Runner {
     prof_e1 = nullptr;
   }
 
-  void attn(int heads, const float* bias = nullptr, const float* gate = nullptr) {
+  // padded: the Conformer attention at width p.da != p.d (head size rounded up to a built one): q | k | v rows in QKp, context in ATTp
+  void attn(int heads, const float* bias = nullptr, const float* gate = nullptr, bool padded = false) {
     if (rc) return;
     AttnArgs a{};
     a.bias = bias; a.gate = gate;
-    a.QK = buf(p.QK); a.ldqk = 3 * p.d; a.lead = p.lead; a.V = buf(p.QK) + 2 * p.d; a.ldv = 3 * p.d; a.O = buf(p.ATT); a.ldo = p.d;
-    a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = p.d;
+    const int w = padded ? p.da : p.d;
+    bf16_t* qk = buf(padded ? p.QKp : p.QK);
+    a.QK = qk; a.ldqk = 3 * w; a.lead = p.lead; a.V = qk + 2 * w; a.ldv = 3 * w; a.O = buf(padded ? p.ATTp : p.ATT); a.ldo = w;
+    a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = w;
     prof_begin();
     const int r = wfl_launch_attention(a, s);
     prof_end(2040, 4.0 * (double)p.B * p.T * (double)p.T * (double)p.d);
-    if (r) rc = fail(r, "attention launch failed (" + std::to_string(r) + "; head_dim " + std::to_string(p.d / heads) + ")");
+    if (r) rc = fail(r, "attention launch failed (" + std::to_string(r) + "; head_dim " + std::to_string(w / heads) + ")");
   }
 
   ZeroMulti zm{};
@@ -1342,6 +1381,10 @@ static int begin_forward(Runner& R, bool with_encoder) {
   R.zero_add(p.ATT, d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.QK, 3 * d, p.lead, p.P, p.T, p.tail);
   R.zero_add(p.FF, p.ffw, p.lead, p.P, p.T, p.tail);
+  if (p.da != d) {
+    R.zero_add(p.QKp, 3 * p.da, p.lead, p.P, p.T, p.tail);
+    R.zero_add(p.ATTp, p.da, p.lead, p.P, p.T, p.tail);
+  }
   if (with_encoder && a.encoder_type == WFL_ENC_WHISPER) {
     R.zero_add(p.mel, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
     R.zero_add(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
@@ -1576,9 +1619,15 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
       R.ln_gemm(H, S, C.ff1_ln, C.ff1_a, C.ff1_a_ln, (int)Mrows, FF, p.ffw, WFL_ACT_GELU);
       R.gemm(FF + (long)p.lead * p.ffw, p.ffw, C.ff1_b, (int)Mrows, p.P, p.T, H, d, p.lead, p.P, WFL_ACT_NONE, H, d, 0.5f);
       // x = LN1(x + MHA(x))
-      R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
-      R.attn(a.conformer_heads);
-      R.gemm(ATT + (long)p.lead * d, d, C.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+      if (p.da == d) {
+        R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
+        R.attn(a.conformer_heads);
+        R.gemm(ATT + (long)p.lead * d, d, C.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+      } else {
+        R.gemm(H + (long)p.lead * d, d, C.qkv, (int)Mrows, p.P, p.T, R.buf(p.QKp), 3 * p.da, p.lead, p.P);
+        R.attn(a.conformer_heads, nullptr, nullptr, true);
+        R.gemm(R.buf(p.ATTp) + (long)p.lead * p.da, p.da, C.out, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_NONE, H, d, 1.f);
+      }
       R.ln(S, H, C.ln1, true);
       // x = x + pw2(GELU(BN(conv_k(GLU(pw1(LN2(x)))))))
       R.ln(H, S, C.ln2);
