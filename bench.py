@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--cpu-calls", type=int, default=5)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the HIP-event pass that times every launch")
     ap.add_argument("--no-h2d", action="store_true", help="skip the with-H2D leg")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also gather every step's packed tags on rank 0 with one RCCL collective (wfl_asr_amd.dist.gather_packed). "
+                         "Off by default: the path shards by clip and has no exchange step -- every rank keeps its own tags, as "
+                         "infer_folder under torchrun writes its own .lab files")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per step and workspace slot instead of launching eagerly (measured gain < 1 %%)")
     ap.add_argument("--inflight", type=int, default=2,
@@ -200,10 +204,12 @@ def main():
     T = model.num_frames(L)
     words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
     nfl = max(1, args.inflight)
-    host_bufs = [torch.empty((world if rank == 0 else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
+    gather_on = (world > 1 and args.gather) or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))
+    host_bufs = [torch.empty((world if (rank == 0 and gather_on) else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
     step_no = [0]
-    multi = world > 1 or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))     # (the env var walks the N > 1 code path on one rank)
+    # the optional gather leg (--gather); WFL_BENCH_FAKE_WORLD walks its code path on one rank
+    multi = (world > 1 and args.gather) or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))
     comm_stream = [torch.cuda.Stream(dev)] if multi else [None]
     gather_bufs = [torch.empty(world, words, dtype=torch.int32, device=dev) for _ in range(nfl)] if (multi and rank == 0) else None
 
@@ -374,7 +380,10 @@ def main():
                 enc_name, "%d-layer BiLSTM + " % m["bilstm_num_layer"] if m["enable_bilstm"] else "", m["num_conformer_layers"],
                 " + %d dilated convs" % m["dilated_conv_depth"] if m["enable_dilated_conv"] else "", B, clip_seconds),
                 "clips_per_gpu": B, "clip_seconds": clip_seconds, "frames_per_clip": T, "tags": len(labels),
-                "parallelism": f"clip-sharded dp{world}", "launch": "hip graph replay" if use_graph else "eager",
+                "parallelism": f"clip-sharded dp{world}",
+                "collective": ("one RCCL gather of the packed tags per step" if multi else
+                               "none on the data path (every rank keeps its own tags); barrier + max-reduce of the clock only"),
+                "launch": "hip graph replay" if use_graph else "eager",
                 "batches_in_flight": nfl},
             "roofline": roof,
         }
