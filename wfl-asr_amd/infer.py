@@ -52,7 +52,7 @@ def pick_device(device="cuda") -> torch.device:
 class Labeler:
     """Model + sidecar files loaded once; `label_files` runs the batched hot loop."""
 
-    def __init__(self, config_path, checkpoint_path, device="cuda", batch_size=16, use_graph=False):
+    def __init__(self, config_path, checkpoint_path, device="cuda", batch_size=None, use_graph=False):
         self.config = load_config(config_path) if isinstance(config_path, (str, os.PathLike)) else config_path
         if torch.device(device).type == "cuda" and not torch.cuda.is_available():
             raise RuntimeError("no ROCm device visible")
@@ -77,6 +77,11 @@ class Labeler:
         if self.lang2id:
             # `lang_id=None` averages over the ids langs.txt lists, in file order (infer.py:147-156, 266-276)
             self.model.set_average_languages(list(self.lang2id.values()))
+        if batch_size is None:
+            # rows per forward.  A BiLSTM's recurrence costs the same ~1.2 us per time step for 16 clips as for 64 (clips run in
+            # groups of 16 on their own workgroups), so wide batches amortise it: default head, 64 rows 96 k audio-s/s, 16 rows 70 k
+            # (DESIGN.md section 5).  A clip's tags do not depend on what shares its batch (bit-exact batch invariance).
+            batch_size = int(os.environ.get("WFL_BATCH_SIZE", "64" if self.model.head_cfg["enable_bilstm"] else "16"))
         self.batch_size = int(batch_size)
         self.use_graph = bool(use_graph)
         self._pinned = None
