@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
   a.U = wfl_lstm_units_per_wg(H); a.error = err;
 #ifdef WFL_LSTM_STAMPS
   a.stamps = st;
+  a.team_shift = getenv("LSTM_TEAM_SHIFT") ? atoi(getenv("LSTM_TEAM_SHIFT")) : 0;
 #endif
   for (int i = 0; i < 2; ++i) { int r = wfl_launch_lstm(a, ex, 0); if (r) { printf("launch failed %d\n", r); return 1; } }
   hipDeviceSynchronize();
@@ -50,6 +51,23 @@ int main(int argc, char** argv) {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   unsigned e; hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost);
   printf("H %d B %d T %d U %d G %d: %.3f ms per launch = %.3f us per step (error word %u)\n", H, B, T, a.U, H / a.U, ms / reps, 1e3 * ms / reps / T, e);
+  {   // the roll call of the last launch: which XCD every slice of every (direction, group) team ran on
+    const int groups = (B + 15) / 16, G = H / a.U;
+    std::vector<unsigned long long> roll((size_t)2 * groups * 64);
+    hipMemcpy(roll.data(), (unsigned long long*)ex + 2L * groups * 2 * 16 * (H / 2), roll.size() * 8, hipMemcpyDeviceToHost);
+    int together = 0;
+    for (int t = 0; t < 2 * groups; ++t) {
+      bool same = true;
+      for (int sl = 1; sl < G; ++sl) same = same && (unsigned)roll[(size_t)t * 64 + sl] == (unsigned)roll[(size_t)t * 64];
+      together += same;
+      if (getenv("LSTM_BENCH_ROLL")) {
+        printf("  team dir %d group %d: XCC", t / groups, t % groups);
+        for (int sl = 0; sl < G; ++sl) printf(" %u", (unsigned)roll[(size_t)t * 64 + sl] - 1u);
+        printf("\n");
+      }
+    }
+    printf("  teams on one XCD: %d of %d\n", together, 2 * groups);
+  }
 #ifdef WFL_LSTM_STAMPS
   std::vector<unsigned long long> h(32 * 8);
   hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);

@@ -101,6 +101,7 @@ struct LstmArgs {
   unsigned long long* roll;        // roll-call granules: [2 dir][groups][64]
 #ifdef WFL_LSTM_STAMPS
   unsigned long long* stamps;      // diagnostic build (tools/micro/lstm_bench.hip): [steps 64..95][8] phase stamps of WG (0,0,0) wave 0
+  int team_shift;                  // diagnostic build: the first team_shift team slots of the grid stay empty (moves the teams to other XCDs)
 #endif
 };
 

@@ -7,7 +7,8 @@
 // with the gate rows reordered unit-major / gate-minor so that one float4 holds (i,f,g,o) of one hidden unit.
 // This kernel only runs the recurrence  gates_t = gx_t + W_hh h_{t-1}  as a persistent launch:
 //
-//   grid = (G slices of the hidden units) x (groups of 16 clips) x (2 directions), 256 threads = 4 waves, one WG per CU.
+//   grid = (G slices of the hidden units) x (groups of 16 clips) x (2 directions), 320 threads = 4 compute waves + 1 loader wave,
+//   one WG per CU.
 //   * W_hh lives in REGISTERS for all T steps: WG (slice, group, dir) owns the 4U x H slice of U = 32 units, each wave
 //     the MFMA A-operand fragments of its two 16-row tiles (4 units x 4 gates each): 2 x H/32 bf16x8 per lane
 //     (64 VGPRs at H = 256, 160 at H = 640).  Round 1 kept a 64-unit slice in LDS and re-read 128 KiB of it per step
@@ -22,7 +23,7 @@
 //     16-byte loads (two granules each) until every tag shows the step they wait for, strip the tags into a
 //     fragment-ordered LDS image (one ds_write_b128 per K step and lane), pass ONE workgroup barrier and read their MFMA B
 //     fragments back.  Round 1's hand-off (1 KiB sc1 stores, vmcnt(0) drain, agent-scope counter add, one polling lane,
-//     barrier, sc1 fragment loads by every wave) cost ~5.8 us per step; this one 1.15 us (H = 256).  A wave's granule stores
+//     barrier, sc1 fragment loads by every wave) cost ~5.8 us per step; this one 0.98 us (H = 256).  A wave's granule stores
 //     cover whole 128-byte lines (image layout [block of 8 units][clip][4 granules]: one store instruction = 512 contiguous
 //     bytes); with 32-byte pieces of four different lines per instruction the same step took 2.44 us.
 //     Ping-pong (two granule images, two LDS images) is WAR-safe: nobody can publish step s+2 before every WG consumed
@@ -31,8 +32,11 @@
 //     direction) team land on ONE XCD.  The team verifies that with a roll call at kernel start (each slice publishes its XCC id);
 //     when it holds, the per-step granules are stored with the default cache policy -- they stay in the XCD's L2 and the consumers'
 //     sc1 loads hit them there -- instead of written through to memory and fetched back: poll 0.60 -> 0.32 us, step 1.76 -> 1.15 us
-//     (H = 256).  When it does not hold the team keeps the write-through stores, which are correct under any placement.
-//   * gx of the next four steps is prefetched into a register ring (HBM latency > one step).
+//     (H = 256, before the loader wave).  When it does not hold the team keeps the write-through stores, which are correct under any placement.
+//   * gx (the input projection's pre-activations, 8 KiB per workgroup and step, from HBM) is streamed by a FIFTH wave: LDS-DMA into
+//     an eight-slot LDS ring, six steps ahead; the compute waves start a step from one ds_read_b128 per tile.  Loaded by the compute
+//     waves themselves (a register ring refilled behind each poll) those HBM loads sat in front of the NEXT step's poll in the
+//     wave's in-order vmcnt queue: +0.17 us per step at 16 clips, +0.43 at 64.  Now 0.98 us per step (16 clips), 1.24 (64).
 //   A poll that gives up ORs bit 0 into the forward's error word (wfl_asr.h: status) instead of hanging the GPU, and the
 //   launch finishes without further waiting.  Launches are cut so that one launch never needs more than 128 resident
 //   workgroups: two such launches (two batches in flight on two streams) always fit the 256 CUs together.
@@ -47,7 +51,7 @@ static __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_
 static __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 #ifdef WFL_LSTM_STAMPS
-#define LSTAMP(k) do { if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && s >= 64 && s < 96) \
+#define LSTAMP(k) do { if (p.stamps && tl == 0 && slice == 0 && tid == 0 && s >= 64 && s < 96) \
     p.stamps[(s - 64) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define LSTAMP(k) do { } while (0)
@@ -58,13 +62,25 @@ static __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __
 #define LSTM_STAGGER 4           // s_sleep units (64 clocks) between two poll attempts
 #endif
 
+typedef __attribute__((address_space(1))) const void* lstm_gptr_t;
+typedef __attribute__((address_space(3))) void* lstm_lptr_t;
+#define LSTM_DL 6              // steps of gx the loader wave keeps in flight
+#define LSTM_NR 8              // slots of the gx ring in LDS (a power of two, >= LSTM_DL + 2)
+#define LSTM_THREADS 320       // four compute waves + the loader wave
+#ifndef LSTM_GX_AUX
+#define LSTM_GX_AUX 0          // cache policy of the gx stream (2 = nt)
+#endif
+
 template <int H, int MAXT>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
-__global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
+__global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   static_assert(MAXT % 2 == 0, "tiles are paired");
   constexpr int KS = H / 32;                     // K steps of 32 hidden units
-  constexpr int D = 4;                           // gx prefetch distance (steps)
   constexpr int NP = MAXT / 2;                   // tile pairs per wave
   __shared__ bf16x8 hfrag[2][KS][64];            // h_{t-1} as MFMA B fragments: [parity][K step][lane]
+  // gx ring: [slot][compute wave][tile][lane] float4 = the (i, f, g, o) pre-activations a lane starts a step from, brought in by the
+  // loader wave's LDS-DMA (dynamic shared memory: LSTM_NR x 4 x MAXT KiB)
+  extern __shared__ __attribute__((aligned(16))) char lstm_dyn[];
+  f32x4* gxl = (f32x4*)lstm_dyn;
   __shared__ int dflag;
   __shared__ int xcd_flag;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -73,7 +89,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
   // 1-D grid laid out for the observed round-robin placement (blocks b and b + 8 share an XCD): all G slices of a (group, direction)
   // team get linear ids congruent mod 8.  Placement is NOT a contract, so the team checks it (roll call below) before relying on it.
   const int U = p.U, G = p.G;
+#ifdef WFL_LSTM_STAMPS
+  const int tl = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / G) - p.team_shift;
+  if (tl < 0) return;
+#else
   const int tl = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / G);       // team of this launch
+#endif
   const int slice = (blockIdx.x >> 3) % G;
   if (tl >= 2 * p.ngroups_launch) return;
   const int grp = p.grp0 + (tl >> 1), dir = tl & 1;
@@ -84,7 +105,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
   // 8 pp + 2 (a >> 2) + e; the lane supplies k = 32 ks + 8 g .. + 8.
   bf16x8 w[MAXT][KS];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
+  for (int i = 0; i < MAXT && wid < 4; ++i) {
     // (a wave whose pair index is beyond the slice -- only with the narrow slices of the test hook -- runs the same code on
     // the last valid pair's data and stores nothing: no per-tile control flow inside the step)
     const int pp = wid + 4 * (i >> 1) < npair ? wid + 4 * (i >> 1) : npair - 1, e = i & 1;
@@ -151,32 +172,50 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
     if (dflag) dead = true;
   }
 
-  // gx register ring: gxv[r][i] = pre-activations (i,f,g,o) of this lane's unit of tile i at step s, s % D == r
-  f32x4 gxv[D][MAXT];
+  // ---- the input projection's pre-activations gx: wave 4 streams them from HBM into the LDS ring with LDS-DMA, LSTM_DL steps ahead.
+  // They used to be loaded by the compute waves themselves (a register ring refilled after each poll), but a wave's vector-memory
+  // operations retire in issue order: the NEXT step's granule poll then sat behind HBM loads that take longer than a step (1-2 us
+  // against 0.7), +0.17 us per step at 16 clips and +0.43 at 64 (tools/micro/lstm_bench.hip, -DWFL_LSTM_NO_GX).  The loader wave has
+  // its own vmcnt; it joins the compute waves' one barrier per step, in front of which it has seen step s + 1's data land.
   const float* gx_lane = p.gx + (p.lead + (long)clip_rd * p.P) * p.ldgx + dir * 4 * H + 4 * (slice * U + 2 * g);
-  auto load_gx = [&](int s, auto rc) __attribute__((always_inline)) {
-    constexpr int r = decltype(rc)::value;
-    const int t = dir == 0 ? s : p.T - 1 - s;
-    const float* gp = gx_lane + (long)t * p.ldgx;
+  if (wid == 4) {
+    auto issue = [&](int s) __attribute__((always_inline)) {
+      const int t = dir == 0 ? s : p.T - 1 - s;
+      const float* gp = gx_lane + (long)t * p.ldgx;
+      char* dst = lstm_dyn + (long)(s & (LSTM_NR - 1)) * (4 * MAXT * 1024);
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int pp = wid + 4 * (i >> 1) < npair ? wid + 4 * (i >> 1) : npair - 1;
-      gxv[r][i] = *(const f32x4*)(gp + 4 * (8 * pp + (i & 1)));
+      for (int w4 = 0; w4 < 4; ++w4)
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+          const int pp = w4 + 4 * (i >> 1) < npair ? w4 + 4 * (i >> 1) : npair - 1;
+#ifndef WFL_LSTM_NO_GX
+          __builtin_amdgcn_global_load_lds((lstm_gptr_t)(gp + 4 * (8 * pp + (i & 1))), (lstm_lptr_t)(dst + (w4 * MAXT + i) * 1024), 16, 0, LSTM_GX_AUX);
+#endif
+        }
+    };
+    for (int s = 0; s < LSTM_DL && s < p.T; ++s) issue(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // (the compute waves' barrier in front of step 0)
+    for (int s = 1; s < p.T; ++s) {
+      // in front of barrier s: steps <= s + 1 have landed; steps s + 2 .. s + LSTM_DL - 1 may still be in flight
+      if (s + LSTM_DL - 1 < p.T) {
+        issue(s + LSTM_DL - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LSTM_DL - 2) * 4 * MAXT) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
     }
-  };
-  if (0 < p.T) load_gx(0, std::integral_constant<int, 0>{});
-  if (1 < p.T) load_gx(1, std::integral_constant<int, 1>{});
-  if (2 < p.T) load_gx(2, std::integral_constant<int, 2>{});
-  if (3 < p.T) load_gx(3, std::integral_constant<int, 3>{});
+    return;
+  }
   __syncthreads();
 
-  auto step = [&](int s, auto rc) __attribute__((always_inline)) {
-    constexpr int r = decltype(rc)::value;
+  auto step = [&](int s) __attribute__((always_inline)) {
     const int t = dir == 0 ? s : p.T - 1 - s;
     f32x4 acc[MAXT];
     bf16x8 hf[KS];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) acc[i] = gxv[r][i];
+    for (int i = 0; i < MAXT; ++i) acc[i] = gxl[(((s & (LSTM_NR - 1)) * 4 + wid) * MAXT + i) * 64 + lane];
     LSTAMP(0);
 
     if (s > 0) {
@@ -250,9 +289,6 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
         }
 #endif
       }
-      // refill the gx slot just consumed -- AFTER the poll: vmcnt retires in issue order, so a poll behind these HBM loads
-      // would wait for them as well
-      if (s + D < p.T) load_gx(s + D, rc);
       __syncthreads();
       LSTAMP(2);
       if (dflag) dead = true;
@@ -261,7 +297,6 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) hf[ks] = hfrag[par][ks][lane];
     } else {
-      if (D < p.T) load_gx(D, rc);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) hf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // h_{-1} = 0
     }
@@ -301,24 +336,31 @@ __global__ __launch_bounds__(256) void lstm_kernel(LstmArgs p) {
           if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, 0);        // stays in the team's L2
           else __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, LSTM_SC1);          // write-through: any placement
         }
+#ifndef WFL_LSTM_NO_OUT       // (diagnostic builds: tools/micro/lstm_bench.hip)
         if (clip < p.B) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
+#endif
       }
     }
     LSTAMP(4);
   };
 
-  for (int s0 = 0; s0 < p.T; s0 += D) {
-    step(s0, std::integral_constant<int, 0>{});
-    if (s0 + 1 < p.T) step(s0 + 1, std::integral_constant<int, 1>{});
-    if (s0 + 2 < p.T) step(s0 + 2, std::integral_constant<int, 2>{});
-    if (s0 + 3 < p.T) step(s0 + 3, std::integral_constant<int, 3>{});
-  }
+  for (int s = 0; s < p.T; ++s) step(s);
 }
 
 template <int H, int MAXT>
 static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
   const int teams = 2 * groups;
-  hipLaunchKernelGGL((lstm_kernel<H, MAXT>), dim3(8 * a.G * ((teams + 7) / 8)), dim3(256), 0, s, a);
+  constexpr int lds = LSTM_NR * 4 * MAXT * 1024;       // the gx ring (dynamic; the fragment images are static shared memory)
+  auto k = lstm_kernel<H, MAXT>;
+  static WflOncePerDevice attr_once;
+  if (attr_once.need()) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+  }
+#ifdef WFL_LSTM_STAMPS
+  hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + a.team_shift + 7) / 8)), dim3(LSTM_THREADS), lds, s, a);
+#else
+  hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + 7) / 8)), dim3(LSTM_THREADS), lds, s, a);
+#endif
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
