@@ -42,7 +42,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0        # /opt/skills/guides/MI355X_MICROARCH.md: 
 # per-GPU batch and clip length of the BASELINE configs (cfg3 64 x 10 s, cfg4 512 / 8, cfg5 256 / 8)
 CONFIG_SHAPE = {1: (16, 30.0), 2: (64, 10.0), 3: (64, 30.0), 4: (32, 30.0)}
 OTHER_KEYS = {2040: "attention (attn_kernel*)", 2041: "BiLSTM recurrence (lstm_kernel)", 2042: "log-mel (logmel_*_kernel)",
-              2043: "LayerNorm (layernorm_kernel)"}
+              2043: "LayerNorm (layernorm_kernel)", 2044: "positional conv (posconv_kernel)"}
 
 
 def parse():

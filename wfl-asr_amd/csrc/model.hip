@@ -62,6 +62,12 @@ struct Conv0Args {
 };
 int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s);
 int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s);
+struct PosConvArgs {               // posconv.hip
+  const bf16_t* xg; long R; long lead; int B, P, T; int groups, cpg, taps;
+  const bf16_t* w[16]; const float* bias[16]; long ldw;
+  const bf16_t* res; const bf16_t* res_lo; bf16_t* out; bf16_t* out_lo; long ld;
+};
+int wfl_launch_posconv(const PosConvArgs& a, hipStream_t s);
 int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s);
 int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
                            const float* b8, const float* cst, float* gate, hipStream_t s);
@@ -1496,7 +1502,23 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
         const int r = wfl_launch_regroup(X, d, G, cpg, p.R, p.lead, B, p.P, p.T, XG, R.s);
         if (r) return fail(r, "regroup launch failed");
       }
-      for (int gi = 0; gi < G; ++gi)
+      // all groups in one tap-stationary launch (posconv.hip); WFL_POSCONV_GEMM=1 keeps rounds 1-2's GEMM per group (A/B runs)
+      static int as_gemm = -1;
+      if (as_gemm < 0) { const char* e = getenv("WFL_POSCONV_GEMM"); as_gemm = e && atoi(e) ? 1 : 0; }
+      int taken = 1;
+      if (!as_gemm && !R.rc && G <= 16) {
+        PosConvArgs pc{};
+        pc.xg = XG; pc.R = p.R; pc.lead = p.lead; pc.B = B; pc.P = p.P; pc.T = p.T; pc.groups = G; pc.cpg = cpg; pc.taps = K;
+        for (int gi = 0; gi < G; ++gi) { pc.w[gi] = m->posconv[gi].W; pc.bias[gi] = m->posconv[gi].bias; }
+        pc.ldw = m->posconv[0].K;
+        pc.res = X; pc.res_lo = R.lo_in(X); pc.out = Y; pc.out_lo = R.lo_of(Y); pc.ld = d;
+        R.prof_begin();
+        taken = wfl_launch_posconv(pc, R.s);
+        R.prof_end(2044, 2.0 * (double)B * p.T * (double)d * (double)cpg * (double)K);
+        if (taken < 0) return fail(taken, "posconv launch failed");
+        if (taken == 0) { R.lo_ok[1] = true; R.stats_for = nullptr; }
+      }
+      for (int gi = 0; gi < G && taken == 1; ++gi)
         R.gemm(XG + ((long)gi * p.R + p.lead - K / 2) * 64, 64, m->posconv[gi], (int)Mrows, p.P, p.T, Y + gi * cpg, d, p.lead, p.P,
                WFL_ACT_GELU, X + gi * cpg, d, 1.f);
     }
