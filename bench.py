@@ -205,7 +205,7 @@ def main():
     words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
     nfl = max(1, args.inflight)
     gather_on = (world > 1 and args.gather) or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))
-    host_bufs = [torch.empty((world if (rank == 0 and gather_on) else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
+    host_bufs = [torch.zeros((world if (rank == 0 and gather_on) else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
     step_no = [0]
     # the optional gather leg (--gather); WFL_BENCH_FAKE_WORLD walks its code path on one rank
@@ -222,7 +222,8 @@ def main():
         with torch.cuda.stream(streams[slot]):
             out = model.label(wav if x is None else x, lang, threshold=0.5, graph=graph, slot=slot)
             if not multi:
-                host_tags[0].copy_(out.packed, non_blocking=True)
+                if not os.environ.get("WFL_BENCH_NO_D2H"):        # (diagnostic: how much the tag copy's blit kernel costs the step)
+                    host_tags[0].copy_(out.packed, non_blocking=True)
                 return slot
         # N > 1: the forward ran on stream `slot`; the collective and the host copy are issued from ONE separate stream (every
         # RCCL call of this process comes from that stream, in program order), which waits for that forward only, so the next

@@ -114,18 +114,24 @@ class Labeler:
         return out
 
     def _run_batches(self, n_batches, fill, take, lang_id, threshold):
-        """The pipelined hot loop.  Two batches in flight: while the GPU labels batch k on stream k % 2 (own workspace slot,
-        own pinned input and output buffers), the host fills batch k + 1 (`fill(k, pinned_rows) -> (lens, rows used)`) and
-        unpacks batch k - 1 (`take(k, rows, ids[B, T], offsets[B, T, 2])`, views into pinned memory: copy what you keep)."""
+        """The pipelined hot loop.  Two batches in flight on the GPU (stream and workspace slot k % 2, own pinned output buffer),
+        a third one being filled: `fill(k, pinned_rows) -> (lens, rows used)` runs on a worker thread one batch ahead of the
+        launches (the native loader releases the GIL), into a ring of three pinned input buffers, each guarded by the event of its
+        last host-to-device copy; the main thread launches batch k and unpacks batch k - 2 (`take(k, rows, ids[B, T],
+        offsets[B, T, 2])`, views into pinned memory: copy what you keep).  With everything on one thread (round 2's first half)
+        the end-to-end rate of a folder of 30 s files was 82 k audio-s/s against 123 k for batches already resident."""
+        from concurrent.futures import ThreadPoolExecutor
         Bs = self.batch_size
         L = CHUNK_SAMPLES
         T = self.model.num_frames(L)
-        if self._pinned is None:
-            self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(2)]
+        NI = 3
+        if self._pinned is None or len(self._pinned) != NI or self._pinned[0].shape[0] != Bs:
+            self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(NI)]
             self._pinned_out = [torch.empty(Bs * T * 4 + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         use_pipe = not self.use_graph
         pending = [None, None]
+        copied = [None] * NI                               # event behind the last H2D copy out of input buffer i
 
         def finish(slot):
             job = pending[slot]
@@ -139,22 +145,37 @@ class Labeler:
             take(k, n, blob[0:nn].reshape(Bs, T), blob[2 * nn:4 * nn].view(np.float32).reshape(Bs, T, 2))
             pending[slot] = None
 
-        for k in range(n_batches):
-            slot = k % 2 if use_pipe else 0
-            finish(slot)                                   # the buffers of this slot are free again
-            host = self._pinned[slot]
-            lens, n = fill(k, host)
-            stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
-            with torch.cuda.stream(stream):
-                dev_wav = host.to(self.device, non_blocking=True)
-                res = self.model.label(dev_wav, None if lang_id is None else [lang_id] * Bs, threshold=threshold, lens=lens,
-                                       average_languages=lang_id is None, graph=self.use_graph, slot=slot)
-                self._pinned_out[slot].copy_(res.packed, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-            pending[slot] = (k, n, ev)
-        finish(0)
-        finish(1)
+        def fill_job(k):
+            ib = k % NI
+            if copied[ib] is not None:
+                copied[ib].synchronize()                   # (three batches back: long done)
+            return fill(k, self._pinned[ib])
+
+        if n_batches <= 0:
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(fill_job, 0)
+            for k in range(n_batches):
+                lens, n = fut.result()
+                if k + 1 < n_batches:
+                    fut = pool.submit(fill_job, k + 1)
+                slot = k % 2 if use_pipe else 0
+                finish(slot)                               # the output buffer and workspace of this slot are free again
+                host = self._pinned[k % NI]
+                stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
+                with torch.cuda.stream(stream):
+                    dev_wav = host.to(self.device, non_blocking=True)
+                    ev_in = torch.cuda.Event()
+                    ev_in.record(stream)
+                    copied[k % NI] = ev_in
+                    res = self.model.label(dev_wav, None if lang_id is None else [lang_id] * Bs, threshold=threshold, lens=lens,
+                                           average_languages=lang_id is None, graph=self.use_graph, slot=slot)
+                    self._pinned_out[slot].copy_(res.packed, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                pending[slot] = (k, n, ev)
+            finish(0)
+            finish(1)
 
     def _forward_items_by_length(self, items, lang_id, threshold):
         """WavLM: the frame count follows the clip length and the reference never pads WavLM input (padding would change the
@@ -246,13 +267,19 @@ class Labeler:
         remap, _ = self._names_for(lang_name)
         return s, e, remap[ph] if ph.size else ph
 
-    def _label_fast(self, audio_paths, lang_id, threshold):
+    def _label_fast(self, audio_paths, lang_id, threshold, lang_name):
         """Files the native loader takes whole (16 kHz, <= 30 s, <= 2 channels, PCM / float WAV): decoded, normalised and
-        converted by worker threads straight into the pinned batch rows (audio.load_wavs_into), one file per row.  Returns
-        {file index: (ids, offsets, samples)}; every other file is left to the general path."""
+        converted by worker threads straight into the pinned batch rows (audio.load_wavs_into), one file per row; a finished
+        batch's tags go to a second worker thread for the native median filter + BIO decode + segment merge while the next
+        batches run.  Returns {file index: [(start_s, end_s, phoneme)]} (before forced alignment); every other file is left to the
+        general path."""
+        from concurrent.futures import ThreadPoolExecutor
         Bs, L = self.batch_size, CHUNK_SAMPLES
         done = {}
         meta = {}
+        self._names_for(lang_name)                       # (build the cache on this thread)
+        post = ThreadPoolExecutor(max_workers=1)
+        futures = []
         threads = max(1, min(16, (os.cpu_count() or 1)))
 
         def fill(k, host):
@@ -267,11 +294,29 @@ class Labeler:
             meta[k] = ok
             return lens, len(sel)
 
-        def take(k, n, ids, offs):
-            for r, fi, ns in meta.pop(k):
-                done[fi] = (ids[r].copy(), offs[r].copy(), ns)
+        mode = self.config["postprocess"]["merge_segments"]
+        names = self._names_for(lang_name)[1]
 
-        self._run_batches((len(audio_paths) + Bs - 1) // Bs, fill, take, lang_id, threshold)
+        def segments(rows):
+            res = []
+            for fi, ids, offs in rows:
+                s, e, ph = self._segments_of_item(ids, offs, lang_name)
+                ph = ph.astype(np.int32)
+                if mode != "none" and s.size:
+                    s, e, ph = npost.merge_segments(s, e, ph, mode)
+                res.append((fi, npost.to_tuples(s, e, ph, names)))
+            return res
+
+        def take(k, n, ids, offs):
+            futures.append(post.submit(segments, [(fi, ids[r].copy(), offs[r].copy()) for r, fi, ns in meta.pop(k)]))
+
+        try:
+            self._run_batches((len(audio_paths) + Bs - 1) // Bs, fill, take, lang_id, threshold)
+            for f in futures:
+                for fi, seg in f.result():
+                    done[fi] = seg
+        finally:
+            post.shutdown(wait=True)
         return done
 
     def label_files(self, audio_paths, lang_id=None, confidence_threshold=0.0, verbose=True):
@@ -280,9 +325,9 @@ class Labeler:
             raise ValueError(f"Error: Language ID ({lang_id}) is higher than the latest ID ({max(self.lang2id.values())}) "
                              f"of this model.\n Languages and Codes available: {self.lang2id}")
         lang_name = self._lang_name(lang_id)
-        decided_fast = {}                                 # file index -> (ids, offsets, samples): one <= 30 s item, natively loaded
+        decided_fast = {}                                 # file index -> segments of its one <= 30 s item, natively loaded
         if self.model.encoder_type == "whisper" and len(audio_paths) > 0:
-            decided_fast = self._label_fast(audio_paths, lang_id, confidence_threshold)
+            decided_fast = self._label_fast(audio_paths, lang_id, confidence_threshold, lang_name)
         items, owner = [], []
         chunk_lens = []
         for fi, path in enumerate(audio_paths):
@@ -300,10 +345,6 @@ class Labeler:
                 owner.append(fi)
                 chunk_lens.append(n)
         decided = self._forward_items(items, lang_id, confidence_threshold) if items else []
-        for fi, (ids, offs, n) in decided_fast.items():
-            decided.append((ids, offs))
-            owner.append(fi)
-            chunk_lens.append(n)
         results = [[] for _ in audio_paths]
         clock = [0.0] * len(audio_paths)
         for (ids, offs), fi, n in zip(decided, owner, chunk_lens):
@@ -314,14 +355,17 @@ class Labeler:
         names = self._names_for(lang_name)[1]
         final = []
         for fi, path in enumerate(audio_paths):
-            parts = results[fi]
-            s = np.concatenate([p[0] for p in parts]) if parts else np.empty(0)
-            e = np.concatenate([p[1] for p in parts]) if parts else np.empty(0)
-            ph = np.concatenate([p[2] for p in parts]).astype(np.int32) if parts else np.empty(0, np.int32)
-            mode = self.config["postprocess"]["merge_segments"]
-            if mode != "none" and s.size:
-                s, e, ph = npost.merge_segments(s, e, ph, mode)
-            segs = npost.to_tuples(s, e, ph, names)
+            if fi in decided_fast:                        # one <= 30 s item: decoded and merged by the post worker already
+                segs = decided_fast[fi]
+            else:
+                parts = results[fi]
+                s = np.concatenate([p[0] for p in parts]) if parts else np.empty(0)
+                e = np.concatenate([p[1] for p in parts]) if parts else np.empty(0)
+                ph = np.concatenate([p[2] for p in parts]).astype(np.int32) if parts else np.empty(0, np.int32)
+                mode = self.config["postprocess"]["merge_segments"]
+                if mode != "none" and s.size:
+                    s, e, ph = npost.merge_segments(s, e, ph, mode)
+                segs = npost.to_tuples(s, e, ph, names)
             forced = _read_forced(path, verbose)
             if forced is not None:
                 aligned = pp.align_phoneme_list(segs, forced)
