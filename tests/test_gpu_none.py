@@ -151,3 +151,28 @@ def test_labeler_end_to_end_with_mel_front_end(tmp_path):
         segs = _manual(lab, str(d / "wavs" / f"f{i}.wav"), 1, 0.3)
         text = open(d / "labs" / f"f{i}.lab").read()
         assert text == "".join(f"{int(s * 1e7)} {int(e * 1e7)} {ph}\n" for s, e, ph in segs), i
+
+
+@pytest.mark.parametrize("L", [250, 700, 16000 * 2 + 5])
+def test_very_short_clips_through_the_full_head(L):
+    """1, 3 and 101 frames: the BiLSTM's loader wave with fewer steps than its prefetch depth, attention over a single key tile,
+    the k = 31 conv wider than the clip; eager and graph replay agree bit for bit."""
+    cfg = _cfg()
+    m, labels, sd_np = _build(cfg, 6, seed=75)
+    wav = synth.make_batch(940, 5, max(L, 1000), seed=75)[:, :L] * 0.05
+    lang = np.array([0, 1, 1, 0, 1], np.int64)
+    x = torch.from_numpy(np.ascontiguousarray(wav)).cuda()
+    out = m.label(x, lang, threshold=0.4, want_logits=True)
+    T = 1 + L // 320
+    assert tuple(out.logits.shape) == (5, T, len(labels)) and int(out.status.item()) == 0
+    enc, arch = resolve_encoder_arch(cfg["model"], cfg["data"])
+    lg, of = O.forward(torch.from_numpy(np.ascontiguousarray(wav)), torch.from_numpy(lang), O.to_torch_state_dict(sd_np), enc, arch,
+                       synth.head_config(cfg["model"]))
+    scale = max(float(lg.std()), 1.0)
+    assert (out.logits.cpu() - lg).abs().max() <= 0.08 * scale
+    assert (out.offsets.cpu() - of).abs().max() <= 0.03
+    g = m.label(x, lang, threshold=0.4, want_logits=True, graph=True)
+    g = m.label(x, lang, threshold=0.4, want_logits=True, graph=True)          # (second call = a replay)
+    torch.cuda.synchronize()
+    assert torch.equal(g.logits, out.logits) and torch.equal(g.ids, out.ids)
+    m.check(5, L)

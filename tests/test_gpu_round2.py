@@ -295,3 +295,24 @@ def test_whisper_tiny_default_head_runs_its_192_wide_heads_as_256():
     assert int(out.status.item()) == 0
     one = m.label(torch.from_numpy(wav[:1]).cuda(), lang[:1], threshold=0.4, want_logits=True)
     assert torch.equal(one.logits[0], out.logits[0])
+
+
+@pytest.mark.parametrize("L", [700, 1300, 2600])
+def test_wavlm_batches_of_very_short_clips(L):
+    """Clips of 1, 3 and 7 frames, six to a batch: the frame-row pitch (24 rows) is below the 32 rows an epilogue pass of the
+    128-row GEMM covers, so a pass wraps over more than one clip (rounds 1-2 wrapped once: clips from the third on were wrong)."""
+    from cases import tiny_wavlm_config
+    cfg = tiny_wavlm_config(True, enable_bilstm=True)
+    m, labels, sd_np = _build(cfg, 5, seed=67)
+    wav = np.ascontiguousarray(synth.make_batch(870, 6, 4000, seed=67)[:, :L])
+    lang = (np.arange(6) % 2).astype(np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.4, want_logits=True)
+    enc_name, arch = resolve_encoder_arch(cfg["model"])
+    lg, of = O.forward(torch.from_numpy(wav), torch.from_numpy(lang), O.to_torch_state_dict(sd_np), enc_name, arch,
+                       synth.head_config(cfg["model"]))
+    assert tuple(out.logits.shape) == tuple(lg.shape) and lg.shape[1] == m.num_frames(L) <= 8
+    err = (out.logits.cpu() - lg).abs().amax(dim=(1, 2))
+    scale = max(float(lg.std()), 1.0)
+    assert float(err.max()) <= 0.1 * scale, err
+    assert (out.offsets.cpu() - of).abs().max() <= 0.03
+    assert int(out.status.item()) == 0

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
       tt[pass] = t;
       orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
       t += RPP;
-      if (t >= p.P) { t -= p.P; ++b; }       // RPP <= 32 < P
+      while (t >= p.P) { t -= p.P; ++b; }    // (a pitch below RPP = 32 rows -- clips of at most 8 frames -- wraps more than once)
     }
   }
   // Unconditional loads (a branch per load would make hipcc wait vmcnt(0) after each): rows that are not stored

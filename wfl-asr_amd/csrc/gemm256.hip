@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
           tt[pass] = t;
           orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
           t += RPP;
-          if (t >= p.P) { t -= p.P; ++b; }
+          while (t >= p.P) { t -= p.P; ++b; }
         }
       }
       // residual rows are prefetched four passes at a time (all accumulators of the other half are still live, so
