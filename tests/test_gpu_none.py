@@ -153,9 +153,9 @@ def test_labeler_end_to_end_with_mel_front_end(tmp_path):
         assert text == "".join(f"{int(s * 1e7)} {int(e * 1e7)} {ph}\n" for s, e, ph in segs), i
 
 
-@pytest.mark.parametrize("L", [250, 700, 16000 * 2 + 5])
+@pytest.mark.parametrize("L", [250, 700, 63 * 320, 64 * 320, 128 * 320 + 7, 16000 * 2 + 5])
 def test_very_short_clips_through_the_full_head(L):
-    """1, 3 and 101 frames: the BiLSTM's loader wave with fewer steps than its prefetch depth, attention over a single key tile,
+    """1, 3, 64, 65, 129 and 101 frames (one key tile exactly full, one key past it, two tiles and one key): the BiLSTM's loader wave with fewer steps than its prefetch depth, attention over a single key tile,
     the k = 31 conv wider than the clip; eager and graph replay agree bit for bit."""
     cfg = _cfg()
     m, labels, sd_np = _build(cfg, 6, seed=75)

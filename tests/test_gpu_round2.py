@@ -316,3 +316,48 @@ def test_wavlm_batches_of_very_short_clips(L):
     assert float(err.max()) <= 0.1 * scale, err
     assert (out.offsets.cpu() - of).abs().max() <= 0.03
     assert int(out.status.item()) == 0
+
+
+def test_bilstm_recurrence_cut_into_several_launches_is_batch_invariant():
+    """144 clips through the default head at d = 512: nine groups of 16 clips x 2 directions x 8 slices = 144 workgroups, cut into
+    two launches of at most 128 (lstm.hip); every clip must come out exactly as it does in a batch of 16 (one launch, one group)."""
+    cfg = synth.base_config("whisper")                                   # d = 512: H = 256, 8 slices per direction
+    m, labels, _ = _build(cfg, 20, seed=68)
+    g = torch.Generator().manual_seed(68)
+    B, T = 144, 40
+    hidden = torch.randn(B, T, 512, generator=g).cuda()
+    lang = (np.arange(B) % 2).astype(np.int64)
+    whole = m.head(hidden, lang, threshold=0.4, want_logits=True)
+    assert int(whole.status.item()) == 0
+    for lo in (0, 64, 128):
+        part = m.head(hidden[lo:lo + 16].contiguous(), lang[lo:lo + 16], threshold=0.4, want_logits=True)
+        assert torch.equal(part.logits, whole.logits[lo:lo + 16]), lo
+        assert torch.equal(part.ids, whole.ids[lo:lo + 16]) and torch.equal(part.offsets, whole.offsets[lo:lo + 16])
+    assert torch.isfinite(whole.logits).all()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(conformer_kernel_size=3, conformer_ff_expansion=1, conformer_heads=1),
+    dict(conformer_kernel_size=7, conformer_ff_expansion=4, conformer_heads=2, num_conformer_layers=3),
+    dict(conformer_kernel_size=15, dilated_conv_depth=3, dilated_conv_kernel=5, bilstm_num_layer=3),
+    dict(conformer_kernel_size=63, dilated_conv_depth=4, dilated_conv_kernel=3, bilstm_num_layer=1, lang_emb_dim=32, num_languages=1),
+    dict(num_conformer_layers=1, enable_dilated_conv=False, lang_emb_dim=8, num_languages=5),
+], ids=["k3x1h1", "k7x4n3", "k15d3k5l3", "k63d4", "n1e8"])
+def test_head_hyperparameters_other_than_the_defaults(kw):
+    """Every head knob of config.yaml away from its default (kernel sizes, expansion, head count, depths, dilation kernel, LSTM
+    layers, embedding width, language count) on the tiny Whisper encoder, against the oracle."""
+    cfg = tiny_whisper_config(**kw)
+    m, labels, sd_np = _build(cfg, 9, seed=69)
+    wav = synth.make_batch(880, 3, 24000, seed=69)
+    nl = cfg["model"]["num_languages"]
+    lang = (np.arange(3) % nl).astype(np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.4, want_logits=True)
+    enc_name, arch = resolve_encoder_arch(cfg["model"])
+    lg, of = O.forward(torch.from_numpy(wav), torch.from_numpy(lang), O.to_torch_state_dict(sd_np), enc_name, arch,
+                       synth.head_config(cfg["model"]))
+    err = (out.logits.cpu() - lg).abs()
+    scale = max(float(lg.std()), 1.0)
+    print(kw, "err max %.3f mean %.4f std %.2f" % (err.max(), err.mean(), scale))
+    assert err.max() <= 0.08 * scale and err.mean() <= 0.012 * scale
+    assert (out.offsets.cpu() - of).abs().max() <= 0.03
+    assert int(out.status.item()) == 0
