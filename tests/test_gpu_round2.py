@@ -361,3 +361,23 @@ def test_head_hyperparameters_other_than_the_defaults(kw):
     assert err.max() <= 0.08 * scale and err.mean() <= 0.012 * scale
     assert (out.offsets.cpu() - of).abs().max() <= 0.03
     assert int(out.status.item()) == 0
+
+
+def test_default_head_at_whisper_large_width():
+    """The default head behind a 1280-wide encoder (Whisper-large): BiLSTM hidden 640 (20 slice workgroups per direction, the
+    widest register-resident W_hh), Conformer heads of 640 (attention_big), the k = 31 conv at N = 1280.  Head only (wfl_head on
+    random hidden states) against the oracle's head."""
+    cfg = synth.base_config("whisper", whisper_model="local/whisper-large-1l")
+    cfg["model"]["encoder_arch"] = dict(d_model=1280, layers=1, heads=20, ffn=5120, n_mels=128, max_positions=1500)
+    m, labels, sd_np = _build(cfg, 12, seed=70)
+    g = torch.Generator().manual_seed(70)
+    hidden = torch.randn(3, 70, 1280, generator=g)
+    lang = np.array([0, 1, 1], np.int64)
+    out = m.head(hidden.cuda(), lang, threshold=0.4, want_logits=True)
+    lg, of = O.head_forward(hidden, torch.from_numpy(lang), O.to_torch_state_dict(sd_np), synth.head_config(cfg["model"]))
+    err = (out.logits.cpu() - lg).abs()
+    scale = max(float(lg.std()), 1.0)
+    print("d = 1280 head: err max %.3f mean %.4f std %.2f" % (err.max(), err.mean(), scale))
+    assert err.max() <= 0.08 * scale and err.mean() <= 0.012 * scale
+    assert (out.offsets.cpu() - of).abs().max() <= 0.03
+    assert int(out.status.item()) == 0
