@@ -121,6 +121,13 @@ def test_head_only_and_max_label_len_at_mel_width():
     lg, _ = m(x, None)
     lg_ref, _ = O.head_forward(whole.hidden.cpu(), None, sd, hc)
     assert (lg.cpu() - lg_ref).abs().max() <= 0.10 * float(lg_ref.std())
+    # infer.py's `lang_id=None`: mean of logits and offsets over the languages (the head runs once per language on one front-end pass)
+    avg = m.label(x, None, threshold=0.4, average_languages=True, want_logits=True)
+    refs = [O.head_forward(whole.hidden.cpu(), torch.full((2,), l, dtype=torch.int64), sd, hc) for l in range(hc["num_languages"])]
+    lg_ref = torch.stack([r[0] for r in refs]).mean(0)
+    of_ref = torch.stack([r[1] for r in refs]).mean(0)
+    assert (avg.logits.cpu() - lg_ref).abs().max() <= 0.10 * float(lg_ref.std())
+    assert (avg.offsets.cpu() - of_ref).abs().max() <= 0.03
 
 
 def test_labeler_end_to_end_with_mel_front_end(tmp_path):

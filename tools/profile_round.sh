@@ -27,6 +27,8 @@ P4="--steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --infligh
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B $P4 > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $B $P4 > $OUT/pmc_write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B $P4 > $OUT/pmc_sq.log 2>&1 || exit 1
+echo "== files -> .lab end to end"
+timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 2> /dev/null | tail -1 > $OUT/e2e_label_files.txt || exit 1
 echo "== lstm micro"
 (cd $ROOT/tools/micro && ./lstm_bench_stamps > $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 512 64 499 >> $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 384 64 1500 >> $OUT/lstm_step_breakdown.txt 2>&1)
 find $OUT -name "*.csv" | head -30
