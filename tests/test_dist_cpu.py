@@ -1,6 +1,5 @@
 """CPU, world_size 2, gloo: the multi-rank path of the labeler (sharding plan + the single tag gather)."""
 import os
-import socket
 
 import pytest
 import torch
@@ -32,14 +31,17 @@ def test_pack_roundtrip_bit_exact():
 
 
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    """A rendezvous FILE (torch.distributed FileStore): no port to race for, nothing to resolve."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="wfl_gloo_")
+    os.close(fd)
+    os.unlink(path)
+    return path
 
 
 def _worker(rank, world, port, counts, q):
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + str(port), rank=rank, world_size=world)
     try:
         T = 37
         n = counts[rank]
@@ -49,7 +51,7 @@ def _worker(rank, world, port, counts, q):
         off = torch.rand(n, T, 2, generator=g)
         a, b, c = wd.gather_tags(ids, mp_, off, dst=0, counts=counts)
         if rank == 0:
-            q.put((a, b, c))
+            q.put((a.numpy(), b.numpy(), c.numpy()))      # (plain pickled arrays: a shared-memory tensor handle can die with its sender)
         else:
             assert a is ids and b is mp_ and c is off
         dist.barrier()
@@ -65,7 +67,7 @@ def test_gather_tags_world2_gloo(counts):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
     for p in procs:
         p.start()
-    a, b, c = q.get(timeout=120)
+    a, b, c = (torch.from_numpy(x) for x in q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -81,16 +83,14 @@ def test_gather_tags_world2_gloo(counts):
 
 def _worker_packed(rank, world, port, q):
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + str(port), rank=rank, world_size=world)
     try:
         n, T = 3, 29
         g = torch.Generator().manual_seed(500 + rank)
         blob = torch.randint(-2 ** 31, 2 ** 31 - 1, (4 * n * T + 1,), generator=g, dtype=torch.int64).to(torch.int32)
         out = wd.gather_packed(blob, dst=0)
         if rank == 0:
-            q.put(out)
+            q.put(out.numpy())
         else:
             assert out is None
         dist.barrier()
@@ -105,7 +105,7 @@ def test_gather_packed_world2_gloo_is_one_bit_exact_collective():
     procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

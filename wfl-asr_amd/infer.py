@@ -330,13 +330,25 @@ class Labeler:
             decided_fast = self._label_fast(audio_paths, lang_id, confidence_threshold, lang_name)
         items, owner = [], []
         chunk_lens = []
-        for fi, path in enumerate(audio_paths):
-            if fi in decided_fast:
-                continue
+
+        def load_one(path):
             chunks = A.load_items(path, self.sr)            # native: decode, resample, normalise, 30 s chunks (csrc/hostpost.hip)
             if chunks is None:                              # an encoding the native decoder does not take: the Python restatement
                 audio = A.load_clip(path, self.sr)
                 chunks = A.chunk_clip(audio, self.sr)
+            return chunks
+
+        slow = [fi for fi in range(len(audio_paths)) if fi not in decided_fast]
+        if len(slow) > 1:                                   # (the native loader releases the GIL: files decode / resample in parallel)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(slow)))) as ex:
+                loaded = dict(zip(slow, ex.map(lambda fi: load_one(audio_paths[fi]), slow)))
+        else:
+            loaded = {fi: load_one(audio_paths[fi]) for fi in slow}
+        for fi, path in enumerate(audio_paths):
+            if fi in decided_fast:
+                continue
+            chunks = loaded[fi]
             lens = [len(c) for c in chunks]
             if verbose and len(chunks) > 1:
                 print(f"Audio is too long ({sum(lens)/self.sr:.1f}s), splitting...")
