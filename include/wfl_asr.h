@@ -119,7 +119,10 @@ int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
  *   offsets    [B][T][2] fp32 sigmoid sub-frame offsets
  *   logits     [B][T][C] fp32                                (optional)
  *   hidden     [B][T][d] fp32 encoder output                 (optional, parity tests; WFL_ENC_NONE: the mel power, d = n_mels)
- *   WavLM and WFL_ENC_NONE take clips of one length per call (lens must be null): the reference never pads their input.
+ *   lens with WavLM / WFL_ENC_NONE (whose input the reference never pads): clip b is treated as lens[b] samples long through the whole
+ *   forward -- its own waveform / GroupNorm statistics, conv frame counts, attention keys, positional-conv padding and backward-LSTM
+ *   start -- and comes out bit for bit as if it were labelled alone; frames behind its own count are tagged o_id with probability 0.
+ *   With Whisper, lens only says where a clip's samples end inside the 30 s window (the encoder always sees 1500 frames).
  *   status     [1] int32 (device, optional): 0, or a bit mask of device-side errors of THIS forward (bit 0: an
  *              inter-workgroup wait of the BiLSTM recurrence timed out -- the tags are invalid).  Written by the last kernel
  *              of the forward, so it can ride in the same D2H copy as the tags.

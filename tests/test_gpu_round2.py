@@ -381,3 +381,35 @@ def test_default_head_at_whisper_large_width():
     assert err.max() <= 0.08 * scale and err.mean() <= 0.012 * scale
     assert (out.offsets.cpu() - of).abs().max() <= 0.03
     assert int(out.status.item()) == 0
+
+
+@pytest.mark.parametrize("kind", ["wavlm_group", "wavlm_stable", "mel"])
+def test_clips_of_different_lengths_in_one_batch_equal_the_clips_labelled_alone(kind):
+    """WavLM / mel front-ends never see padding in the reference (one clip per forward).  A batch with per-clip sample counts must
+    give every clip exactly what it gets alone: its own waveform / GroupNorm statistics, conv frame counts, attention keys, positional
+    conv padding, backward-LSTM start -- compared bit for bit with B = 1 forwards, full default head."""
+    from cases import tiny_wavlm_config
+    if kind == "mel":
+        cfg = synth.base_config("none")
+        lens = [16000 * 3 + 11, 5000, 16000 * 2, 900, 16000 * 3 + 11, 250, 20480]
+    else:
+        cfg = tiny_wavlm_config(kind == "wavlm_stable", enable_bilstm=True)
+        lens = [16000 * 3 + 11, 5000, 16000 * 2, 900, 16000 * 3 + 11, 401, 20479]
+    m, labels, sd_np = _build(cfg, 7, seed=71)
+    B, L = len(lens), max(lens)
+    wav = synth.make_batch(890, B, L, seed=71) * (0.05 if kind == "mel" else 1.0)
+    for b, n in enumerate(lens):
+        wav[b, n:] = 7.0                                            # whatever lies behind a clip's end must not matter
+    lang = (np.arange(B) % 2).astype(np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.4, lens=lens, want_logits=True, want_hidden=True)
+    assert int(out.status.item()) == 0
+    for b, n in enumerate(lens):
+        one = m.label(torch.from_numpy(np.ascontiguousarray(wav[b:b + 1, :n])).cuda(), lang[b:b + 1], threshold=0.4, want_logits=True,
+                      want_hidden=True)
+        Tb = m.num_frames(n)
+        assert one.logits.shape[1] == Tb
+        assert torch.equal(out.hidden[b, :Tb], one.hidden[0]), (kind, b, "hidden")
+        assert torch.equal(out.logits[b, :Tb], one.logits[0]), (kind, b, "logits")
+        assert torch.equal(out.ids[b, :Tb], one.ids[0]) and torch.equal(out.offsets[b, :Tb], one.offsets[0])
+        assert bool((out.ids[b, Tb:] == m.label2id["O"]).all()) and bool((out.maxprob[b, Tb:] == 0).all())
+    m.check(B, L)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   // XCD-aware order: blocks i and i+8 share an XCD (and its L2).  All query blocks of one (clip, head) read the
   // same K / V^T, so give each XCD a contiguous run of logical blocks ordered (clip, head, query block): K/V are
   // then fetched from HBM once per (clip, head) instead of once per XCD (PMC: 419 MB -> algorithmic 74 MB per launch).
-  const int nqb = (p.T + 4 * QT * 16 - 1) / (4 * QT * 16);
+  const int nqb = (p.T + 4 * QT * 16 - 1) / (4 * QT * 16);     // (grid geometry: the batch-wide frame count)
   const int nblk = nqb * p.heads * p.B;
   int bid = blockIdx.x;
   {
@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   const int qb = bid % nqb;
   const int bh = bid / nqb;
   const int b = bh / p.heads, h = bh - b * p.heads;
+  // a batch of clips of different lengths (AttnArgs::clip_T): this block's clip has its own frame count; keys and queries beyond it
+  // do not exist -- exactly the clip labelled alone
+  const int T = p.clip_T ? p.clip_T[b] : p.T;
+  if (qb * (4 * QT * 16) >= T) return;                          // (block-uniform: before any barrier)
   const int q0 = qb * (4 * QT * 16) + wid * (QT * 16);
   const long row0 = p.lead + (long)b * p.P;
   const bf16_t* Kg = p.QK + p.d + h * HD;                 // + row * ldqk
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     int q = q0 + qt * 16 + c;
-    q = q < p.T ? q : p.T - 1;
+    q = q < T ? q : T - 1;
     const bf16_t* qp = p.QK + (row0 + q) * p.ldqk + h * HD + g * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *(const bf16x8*)(qp + ks * 32);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = f2bf(c == 0 ? 1.0f : 0.0f);
 
-  const int ntiles = (p.T + KT - 1) / KT;
+  const int ntiles = (T + KT - 1) / KT;
   bf16x8 kreg[KCH], vreg[KCH];
 
   // per-lane element offsets inside a tile are fixed; the tile base is block-uniform (scalar base + 32-bit lane offset)
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   constexpr int BT = KT + NQW;                           // table entries per tile (one spare)
   float* btab = (float*)(smem + (PREFETCH ? 2 : 1) * TILE_BYTES);   // [2][BT]
   const int qwg0 = qb * NQW;
-  const float* tabc = BIAS ? p.bias + (long)h * (2 * p.T - 1) + (p.T - 1) : nullptr;
+  const float* tabc = BIAS ? p.bias + (long)h * (2 * p.T - 1) + (p.T - 1) : nullptr;    // (table and gate are laid out for the batch-wide T)
   auto stage_bias = [&](int kt) {
     if (BIAS && tid < BT - 1) {
       int off = kt * KT - qwg0 - (NQW - 1) + tid;        // key - query for entry tid
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       int q = q0 + qt * 16 + c;
-      q = q < p.T ? q : p.T - 1;
+      q = q < T ? q : T - 1;
       gq[qt] = p.gate[((long)b * p.heads + h) * p.T + q];
     }
     stage_bias(0);
@@ -197,12 +201,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) st[qt][kk][e] = fmaf(gq[qt], bt[kk * 16 + e - qt * 16], st[qt][kk][e]);
     }
-    if (kt * KT + KT > p.T) {            // last tile: keys >= T do not exist
+    if (kt * KT + KT > T) {            // last tile: keys >= T do not exist
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (kt * KT + kk * 16 + g * 4 + e >= p.T) {
+          if (kt * KT + kk * 16 + g * 4 + e >= T) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) st[qt][kk][e] = -INFINITY;
           }
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const float l = __shfl(osum[qt][0], c);          // row sum of query c lives in lane (g = 0, c), register 0
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + c;
-    if (q < p.T) {
+    if (q < T) {
       bf16_t* op = p.O + (row0 + q) * p.ldo + h * HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {

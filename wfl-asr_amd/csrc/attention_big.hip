@@ -31,19 +31,21 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
   }
   const int qb = bid % nqb, bh = bid / nqb;
   const int b = bh / p.heads, h = bh - b * p.heads;
+  const int T = p.clip_T ? p.clip_T[b] : p.T;      // (a batch of clips of different lengths: this block's clip, attention.hip)
+  if (qb * 64 >= T) return;
   const int q0 = qb * 64 + wid * 16;
   const long row0 = p.lead + (long)b * p.P;
   const bf16_t* Kg = p.QK + p.d + h * HD;
   const bf16_t* Vg = p.V + h * HD;
   int qrow = q0 + c;
-  qrow = qrow < p.T ? qrow : p.T - 1;
+  qrow = qrow < T ? qrow : T - 1;
   const bf16_t* qp = p.QK + (row0 + qrow) * p.ldqk + h * HD + g * 8;
 
   f32x4 o[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun = -INFINITY, lrun = 0.f;
-  const int ntiles = (p.T + KTL - 1) / KTL;
+  const int ntiles = (T + KTL - 1) / KTL;
 
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();
@@ -72,12 +74,12 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
         st[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, st[kk], 0, 0, 0);
       }
     }
-    if (kt * KTL + KTL > p.T) {
+    if (kt * KTL + KTL > T) {
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (kt * KTL + kk * 16 + g * 4 + e >= p.T) st[kk][e] = -INFINITY;
+          if (kt * KTL + kk * 16 + g * 4 + e >= T) st[kk][e] = -INFINITY;
     }
     float mx = st[0][0];
 #pragma unroll
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_big_kernel(AttnArgs p) {
   l += __shfl_xor(l, 32);
   const float inv = 1.0f / l;
   const int q = q0 + c;
-  if (q < p.T) {
+  if (q < T) {
     bf16_t* op = p.O + (row0 + q) * p.ldo + h * HD + g * 4;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {

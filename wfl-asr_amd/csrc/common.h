@@ -68,6 +68,8 @@ struct GemmArgs {
   int stats_nsl;            //   instead of summing the fragments in the kernel; stats_nsl = tiles per row (producer's N / 256)
   long stats_lead;
   void* trash;              // set by the launcher: >= 1 KiB scratch line for stores that must not land (gemm_stream.hip)
+  const int* clip_T;        // [clips] valid frames of clip b (<= T), or null: every clip has T.  Rows t >= clip_T[b] are not stored --
+                            //   batches of clips of different lengths behind the WavLM / mel front-ends (model.hip, "ragged")
 #ifdef WFL_GEMM_STAMPS
   unsigned long long* stamps;   // diagnostic build: [blocks][8]
 #endif
@@ -84,6 +86,7 @@ struct AttnArgs {
   int B, T, P, heads, d;
   const float* bias;      // optional additive score bias (WavLM gated rel-pos), see attention.hip
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
+  const int* clip_T;      // [B] valid frames per clip (keys and queries >= clip_T[b] do not exist), or null: T for all
 };
 
 // One BiLSTM layer's recurrence (lstm.hip)
@@ -99,6 +102,8 @@ struct LstmArgs {
   int ngroups;                     // clip groups of the whole batch (exchange indexing)
   int ngroups_launch;              // clip groups of this launch
   unsigned long long* roll;        // roll-call granules: [2 dir][groups][64]
+  const int* clip_T;               // [B] valid frames per clip or null: clip b runs steps 0 .. clip_T[b] - 1, its backward direction
+                                   //   starts at its own last frame; the other steps of a shorter clip compute on and store nothing
 #ifdef WFL_LSTM_STAMPS
   unsigned long long* stamps;      // diagnostic build (tools/micro/lstm_bench.hip): [steps 64..95][8] phase stamps of WG (0,0,0) wave 0
   int team_shift;                  // diagnostic build: the first team_shift team slots of the grid stay empty (moves the teams to other XCDs)

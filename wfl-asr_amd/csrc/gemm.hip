@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     int b = m / p.P, t = m - b * p.P;
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
-      ok[pass] = (m + pass * RPP < p.M) && t < p.T;
+      ok[pass] = (m + pass * RPP < p.M) && t < (p.clip_T ? p.clip_T[b] : p.T);
       tt[pass] = t;
       orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
       t += RPP;

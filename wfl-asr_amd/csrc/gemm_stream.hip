@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       int t = m - b * p.P;
       if (t < 0) { t += p.P; --b; }
       if (t >= p.P) { t -= p.P; ++b; }
-      orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * p.c_pitch + t : -1;
+      orow[u] = (m < p.M && t < (p.clip_T ? p.clip_T[b] : p.T)) ? (int)p.c_lead + b * p.c_pitch + t : -1;
     }
     // residual hi + lo halves: a ring of three 16-frame tiles in flight (all six at once would not fit the register file next
     // to the accumulators); tile u + 3 is requested as soon as tile u has been consumed

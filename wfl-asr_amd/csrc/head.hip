@@ -18,6 +18,8 @@ struct TagArgs {
   float* offsets;                    // [rows][2]
   const unsigned* status_src;        // the forward's device-side error word -> *status_dst (both optional)
   int* status_dst;
+  const int* clip_T; int Tmax;       // [clips] valid frames per clip (rows = clips x Tmax) or null: frames beyond a clip's own count are
+                                     //   tagged "O" with probability 0 and zero offsets, whatever the logits buffer holds there
 };
 
 __global__ __launch_bounds__(256) void tag_decide_kernel(TagArgs p) {
@@ -25,6 +27,16 @@ __global__ __launch_bounds__(256) void tag_decide_kernel(TagArgs p) {
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x == 0 && p.status_dst) *p.status_dst = p.status_src ? (int)*p.status_src : 0;
   if (r >= p.rows) return;
+  if (p.clip_T) {
+    const int b = (int)(r / p.Tmax), t = (int)(r - (long)b * p.Tmax);
+    if (t >= p.clip_T[b]) {
+      if (lane == 0) {
+        if (p.logits) { p.maxprob[r] = 0.f; p.ids[r] = p.o_id; if (p.argmax) p.argmax[r] = p.o_id; }
+        if (p.offsets) { p.offsets[r * 2] = 0.f; p.offsets[r * 2 + 1] = 0.f; }
+      }
+      return;
+    }
+  }
   if (p.logits) {
     const float* lp = p.logits + r * p.ldl;
     float best = -INFINITY;

@@ -67,6 +67,10 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, f0 = blockIdx.x * FT;
   const int len = p.lens ? min(p.lens[b], min(p.L, p.n_samples)) : min(p.L, p.n_samples);
+  // POWER with per-clip lengths: the clip is reflected about ITS last sample and has 1 + len / HOP frames (a clip labelled alone);
+  // the frames up to the batch-wide count are written as zeros
+  const int nsamp = (POWER && p.lens) ? len : p.n_samples;
+  const int nfr = (POWER && p.lens) ? (len > NFFT / 2 ? 1 + len / HOP : 0) : p.n_frames;
   const float* w = p.wav + (long)b * p.ldw;
   LSTAMP(0);
 
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
   for (int it = 0; it < NIT; ++it) {
     int i = s0 + tid + 256 * it;
     if (i < 0) i = -i;
-    if (i >= p.n_samples) i = 2 * (p.n_samples - 1) - i;
+    if (i >= nsamp) i = 2 * (nsamp - 1) - i;
     const bool ok = i >= 0 && i < len;
     const int ic = min(max(i, 0), p.L - 1);
     const float v = w[ic];
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
     const float* mw = tab_lds ? lw + m * p.mel_maxw : p.mel_w + (long)m * p.mel_maxw;
     float acc = 0.f;
     for (int i = 0; i < cnt; ++i) acc += mw[i] * pw[f * PPITCH + lo + i];
-    const float lv = POWER ? acc : log10f(fmaxf(acc, 1e-10f));
+    const float lv = POWER ? (f0 + f < nfr ? acc : 0.f) : log10f(fmaxf(acc, 1e-10f));
     if (fvalid) {
       p.raw[((long)b * p.n_frames + f0 + f) * p.n_mels + m] = lv;
       mx = fmaxf(mx, lv);
@@ -235,10 +239,10 @@ static int launch_power(const LogmelArgs& a, hipStream_t s) {
   return 0;
 }
 
-// encoder_type none: a.raw receives the mel power (= the hidden states, fp32 [B][frames][n_mels]); a.lens must be null (clips of
-// one length per call, reflected about their own last sample like a clip labelled alone), a.n_samples = a.L > 200.
+// encoder_type none: a.raw receives the mel power (= the hidden states, fp32 [B][frames][n_mels]); a.n_samples = a.L > 200; with
+// a.lens every clip is reflected about its own last sample and has its own 1 + len / hop frames (zeros behind them).
 int wfl_launch_melpower(const LogmelArgs& a, int hop, bf16_t* out, long ldo, long lead, int P, int split, int shift, hipStream_t s) {
-  if (a.n_samples != a.L || a.L <= NFFT / 2 || a.n_frames != 1 + a.L / hop || a.n_mels <= 0 || a.B <= 0 || a.lens) return -1;
+  if (a.n_samples != a.L || a.L <= NFFT / 2 || a.n_frames != 1 + a.L / hop || a.n_mels <= 0 || a.B <= 0) return -1;
   int r;
   if (hop == 160) r = launch_power<160, true>(a, s);
   else if (hop == 320) r = launch_power<320, true>(a, s);

@@ -178,9 +178,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   // against 0.7), +0.17 us per step at 16 clips and +0.43 at 64 (tools/micro/lstm_bench.hip, -DWFL_LSTM_NO_GX).  The loader wave has
   // its own vmcnt; it joins the compute waves' one barrier per step, in front of which it has seen step s + 1's data land.
   const float* gx_lane = p.gx + (p.lead + (long)clip_rd * p.P) * p.ldgx + dir * 4 * H + 4 * (slice * U + 2 * g);
+  const int Tc = p.clip_T ? p.clip_T[clip_rd] : p.T;     // frames of this lane's clip (LstmArgs::clip_T)
   if (wid == 4) {
     auto issue = [&](int s) __attribute__((always_inline)) {
-      const int t = dir == 0 ? s : p.T - 1 - s;
+      int t = dir == 0 ? s : Tc - 1 - s;             // (this lane's clip: its backward direction starts at its own last frame)
+      t = s < Tc ? t : 0;                            // steps beyond the clip's length: any valid row, the result is never stored
       const float* gp = gx_lane + (long)t * p.ldgx;
       char* dst = lstm_dyn + (long)(s & (LSTM_NR - 1)) * (4 * MAXT * 1024);
 #pragma unroll
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   __syncthreads();
 
   auto step = [&](int s) __attribute__((always_inline)) {
-    const int t = dir == 0 ? s : p.T - 1 - s;
+    const int t = dir == 0 ? s : Tc - 1 - s;               // (per lane: the clip's own frame, LstmArgs::clip_T)
     f32x4 acc[MAXT];
     bf16x8 hf[KS];
 #pragma unroll
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
           else __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, LSTM_SC1);          // write-through: any placement
         }
 #ifndef WFL_LSTM_NO_OUT       // (diagnostic builds: tools/micro/lstm_bench.hip)
-        if (clip < p.B) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
+        if (clip < p.B && s < Tc) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
 #endif
       }
     }

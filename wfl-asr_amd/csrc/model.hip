@@ -42,6 +42,7 @@ struct TagArgs {
   float* offsets;
   const unsigned* status_src;   // the forward's device-side error word -> *status_dst (both optional)
   int* status_dst;
+  const int* clip_T; int Tmax;
 };
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
 int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s, int split,
@@ -56,25 +57,29 @@ struct Conv0Args {
   const float* bias;
   const float* gamma; const float* beta;
   int B, T0, C;
+  const int* lens;
   double* cstats;
   float* cpart;
   bf16_t* out; long lead; int P;
 };
-int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s);
+int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s, const int* lens = nullptr);
 int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s);
+int wfl_launch_clip_frames(const int* lens, int B, int L, int n, const int* kernel, const int* stride, int min_len, int* out, hipStream_t s);
 struct PosConvArgs {               // posconv.hip
   const bf16_t* xg; long R; long lead; int B, P, T; int groups, cpg, taps;
   const bf16_t* w[16]; const float* bias[16]; long ldw;
   const bf16_t* res; const bf16_t* res_lo; bf16_t* out; bf16_t* out_lo; long ld;
+  const int* clip_T;
 };
 int wfl_launch_posconv(const PosConvArgs& a, hipStream_t s);
-int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s);
+int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s,
+                       const int* clip_T = nullptr);
 int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
                            const float* b8, const float* cst, float* gate, hipStream_t s);
 int wfl_launch_relpos_table(const float* rel_emb, const int* bucket_of_delta, int max_t, int heads, int T, float* table, hipStream_t s);
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
                              int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo = nullptr, bf16_t* y_lo = nullptr,
-                             int n_div = 0);
+                             int n_div = 0, const int* clip_T = nullptr);
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
@@ -1056,7 +1061,7 @@ struct Plan {
   long Rl[8];
   // byte offsets
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
-  long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, QKp, ATTp, total;
+  long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, QKp, ATTp, clipT, total;
   int da;                       // Conformer attention width (wfl_model::conf_da); QKp / ATTp exist when it differs from d
 };
 
@@ -1139,6 +1144,7 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
     p.gx = take(p.R * 4L * p.d * 4);                       // fp32 [rows][8H]
     p.lstm_x = take(wfl_lstm_exchange_bytes(p.d / 2, B));
   }
+  p.clipT = take(8L * B * 4);                            // per-clip frame counts per front-end level (ragged batches), [level][B]
   p.err = take(256);                                     // the forward's device-side error word
   p.total = off;
   return p;
@@ -1168,6 +1174,18 @@ struct Runner {
   int rc = 0;
 
   bf16_t* buf(long off) const { return (bf16_t*)(ws + off); }
+  // Ragged batches (WavLM / mel front-ends with per-clip lengths): clipT = [B] frames of every clip at the encoder's rate,
+  // levelT[i] = the same at level i of the WavLM conv stack (both in the workspace, written by clip_frames_kernel); null otherwise.
+  // Every kernel that stores frame rows skips rows t >= clipT[b]; the shared buffers are zeroed whole at the start of the forward,
+  // so those rows stay zero like the halo rows do, and what a clip sees is exactly what it sees when it is labelled alone.
+  const int* clipT = nullptr;
+  const int* levelT[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int* clip_T_for(int P) const {
+    if (!clipT) return nullptr;
+    if (P == p.P) return clipT;
+    for (int i = 0; i < p.nlev; ++i) if (p.Pl[i] == P) return levelT[i];
+    return nullptr;
+  }
   // Residual stream hi + lo (common.h, GemmArgs::res_lo): X and Y have low halves; lo_ok says whether the low half of the
   // tensor currently held in X / Y is valid (a kernel that writes only the high half invalidates it).
   bool lo_ok[2] = {false, false};
@@ -1207,6 +1225,7 @@ struct Runner {
     g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
     g.W = W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.n_valid;
     g.P = P; g.T = T;
+    g.clip_T = clip_T_for(P);
     g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch;
     g.bias = W.bias; g.clip_bias = clip_bias; g.clip_idx = clip_idx; g.clip_ld = clip_ld;
     g.res = res; g.ldres = ldres; g.alpha = alpha;
@@ -1286,7 +1305,7 @@ struct Runner {
     bf16_t* y_lo = lo_out ? lo_of(y) : nullptr;
     { const int yi = lo_idx(y); if (yi >= 0) lo_ok[yi] = y_lo != nullptr; }
     prof_begin();
-    const int r = wfl_launch_layernorm_act(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, 0, s, x_lo, y_lo, m->dv);
+    const int r = wfl_launch_layernorm_act(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, 0, s, x_lo, y_lo, m->dv, clipT);
     prof_end(2043, 0.0);
     if (r) rc = fail(r, "layernorm launch failed");
   }
@@ -1323,6 +1342,7 @@ struct Runner {
     bf16_t* qk = buf(padded ? p.QKp : p.QK);
     a.QK = qk; a.ldqk = 3 * w; a.lead = p.lead; a.V = qk + 2 * w; a.ldv = 3 * w; a.O = buf(padded ? p.ATTp : p.ATT); a.ldo = w;
     a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = w;
+    a.clip_T = clipT;
     prof_begin();
     const int r = wfl_launch_attention(a, s);
     prof_end(2040, 4.0 * (double)p.B * p.T * (double)p.T * (double)p.d);
@@ -1401,6 +1421,24 @@ static int begin_forward(Runner& R, bool with_encoder) {
   return R.rc;
 }
 
+// Ragged batches: every row of the buffers the stages share starts at zero (begin_forward zeroed their halo rows only); producers skip
+// the rows behind a clip's own frame count, so those stay zero for the whole forward -- for the convolutions' taps and the positional
+// conv's padding they are the same zeros the halo rows are.
+static int zero_shared_buffers(Runner& R) {
+  const Plan& p = R.p;
+  const long d = p.d;
+  int r = wfl_launch_fill_i32((int*)(R.ws + p.X), p.R * d / 2, 0, R.s);
+  if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.Y), p.R * d / 2, 0, R.s);
+  if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.ATT), p.R * d / 2, 0, R.s);
+  if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.QK), p.R * 3 * d / 2, 0, R.s);
+  if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.FF), p.R * (long)p.ffw / 2, 0, R.s);
+  if (!r && p.da != p.d) {
+    r = wfl_launch_fill_i32((int*)(R.ws + p.QKp), p.R * 3L * p.da / 2, 0, R.s);
+    if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.ATTp), p.R * (long)p.da / 2, 0, R.s);
+  }
+  return r ? fail(r, "fill launch failed") : 0;
+}
+
 // Feature extractor + encoder (model.py:149-161): leaves the encoder output in the Y rows.
 static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* lens) {
   wfl_model* m = R.m;
@@ -1437,10 +1475,17 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
   } else if (a.encoder_type == WFL_ENC_NONE) {
     // ---- no encoder: hidden = MelSpectrogram(wav).transpose(1, 2) (model.py:149-150).  Like WavLM input it is never padded by the
     // reference: one clip length per call.
-    if (lens) return fail(-1, "wfl_forward: per-clip lengths are not supported with encoder_type none (batch clips of equal length)");
+    if (lens) {                                        // (every clip keeps its own frame count: Runner::clipT)
+      int* ct = (int*)(R.ws + p.clipT);
+      const int k0 = 0, s0 = a.mel_hop;
+      const int cr = wfl_launch_clip_frames(lens, B, L, 1, &k0, &s0, 201, ct, R.s);
+      if (cr) return fail(cr, "clip_frames launch failed");
+      R.clipT = ct;
+      if (int zr = zero_shared_buffers(R)) return zr;
+    }
     if (L <= 200) return fail(-1, "wfl_forward: encoder_type none needs more than 200 samples (reflect padding of the STFT)");
     LogmelArgs la{};
-    la.wav = wav; la.ldw = ldw; la.lens = nullptr; la.L = L; la.B = B;
+    la.wav = wav; la.ldw = ldw; la.lens = lens; la.L = L; la.B = B;
     la.n_frames = p.T; la.n_samples = L; la.n_mels = a.n_mels;
     la.Wc = m->Wc; la.Ws = m->Ws; la.mel_lo = m->mel_lo; la.mel_cnt = m->mel_cnt; la.mel_w = m->mel_w; la.mel_maxw = m->mel_maxw;
     la.raw = (float*)(R.ws + p.raw); la.clipmax = nullptr;
@@ -1450,15 +1495,23 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     if (r) return fail(r, "mel launch failed");
     R.lo_ok[1] = false;
   } else {
-    // ---- WavLM (HF modeling_wavlm.py:1032-1088).  `lens` is not supported: the reference never pads WavLM input.
-    if (lens) return fail(-1, "wfl_forward: per-clip lengths are not supported with the WavLM encoder (batch clips of equal length)");
+    // ---- WavLM (HF modeling_wavlm.py:1032-1088).  The reference never pads WavLM input: with `lens` every clip keeps its own sample
+    // and frame counts through the whole forward (Runner::clipT), i.e. what it gets when it is labelled alone.
+    if (lens) {
+      int* ct = (int*)(R.ws + p.clipT);
+      const int cr = wfl_launch_clip_frames(lens, B, L, p.nlev, a.wavlm_conv_kernel, a.wavlm_conv_stride, 0, ct, R.s);
+      if (cr) return fail(cr, "clip_frames launch failed");
+      for (int i = 0; i < p.nlev; ++i) R.levelT[i] = ct + (long)i * B;
+      R.clipT = R.levelT[p.nlev - 1];
+      if (int zr = zero_shared_buffers(R)) return zr;
+    }
     if (p.T > WAVLM_MAX_T) return fail(-1, "wfl_forward: clip too long for the WavLM relative-position table");
     const int C = a.wavlm_conv_dim[0], n = p.nlev;
     bf16_t* F[2] = {R.buf(p.FA), R.buf(p.FB)};
     double* wstats = nullptr;
     if (a.wavlm_do_normalize) {
       wstats = (double*)(R.ws + p.wstats);
-      const int r = wfl_launch_wav_stats(wav, ldw, B, L, wstats, R.s);
+      const int r = wfl_launch_wav_stats(wav, ldw, B, L, wstats, R.s, lens);
       if (r) return fail(r, "wav_stats launch failed");
     }
     // Rows that are not valid frames of a level are zeroed before the level is produced (the two buffers alternate
@@ -1468,7 +1521,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     {
       Conv0Args c{};
       c.wav = wav; c.ldw = ldw; c.L = L; c.wstats = wstats; c.w = m->conv0_w; c.bias = m->conv0_b;
-      c.gamma = m->conv0_norm.g; c.beta = m->conv0_norm.b; c.B = B; c.T0 = p.Tl[0]; c.C = C;
+      c.gamma = m->conv0_norm.g; c.beta = m->conv0_norm.b; c.B = B; c.T0 = p.Tl[0]; c.C = C; c.lens = lens;
       c.cstats = (double*)(R.ws + p.cstats); c.cpart = (float*)(R.ws + p.cpart); c.out = F[0]; c.lead = p.leadl[0]; c.P = p.Pl[0];
       const int r = wfl_launch_conv0(c, a.wavlm_group_norm, R.s);
       if (r) return fail(r, "conv0 launch failed");
@@ -1482,14 +1535,15 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       R.gemm(in, 2 * C, m->fconv[i - 1], B * p.Pl[i], p.Pl[i], p.Tl[i], out, C, p.leadl[i], p.Pl[i], group ? WFL_ACT_GELU : WFL_ACT_NONE);
       if (!group && !R.rc) {
         const int r = wfl_launch_layernorm_act(out, C, out, C, m->fconv_ln[i - 1].g, m->fconv_ln[i - 1].b, 1e-5f, p.leadl[i], B,
-                                               p.Pl[i], p.Tl[i], C, 1, R.s);
+                                               p.Pl[i], p.Tl[i], C, 1, R.s, nullptr, nullptr, 0, R.levelT[i]);
         if (r) return fail(r, "layernorm launch failed");
       }
     }
     if (R.rc) return R.rc;
     bf16_t* feats = F[(n - 1) & 1];                    // level n-1 has the main geometry (lead, P, T)
     {
-      const int r = wfl_launch_layernorm_act(feats, C, feats, C, m->fp_ln.g, m->fp_ln.b, 1e-5f, p.lead, B, p.P, p.T, C, 0, R.s);
+      const int r = wfl_launch_layernorm_act(feats, C, feats, C, m->fp_ln.g, m->fp_ln.b, 1e-5f, p.lead, B, p.P, p.T, C, 0, R.s, nullptr, nullptr,
+                                             0, R.clipT);
       if (r) return fail(r, "layernorm launch failed");
     }
     R.next_lo_out = true;
@@ -1499,7 +1553,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       const int G = a.wavlm_pos_conv_groups, cpg = d / G, K = a.wavlm_pos_conv_kernel;
       bf16_t* XG = R.buf(p.XG);
       if (!R.rc) {
-        const int r = wfl_launch_regroup(X, d, G, cpg, p.R, p.lead, B, p.P, p.T, XG, R.s);
+        const int r = wfl_launch_regroup(X, d, G, cpg, p.R, p.lead, B, p.P, p.T, XG, R.s, R.clipT);
         if (r) return fail(r, "regroup launch failed");
       }
       // all groups in one tap-stationary launch (posconv.hip); WFL_POSCONV_GEMM=1 keeps rounds 1-2's GEMM per group (A/B runs)
@@ -1512,6 +1566,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
         for (int gi = 0; gi < G; ++gi) { pc.w[gi] = m->posconv[gi].W; pc.bias[gi] = m->posconv[gi].bias; }
         pc.ldw = m->posconv[0].K;
         pc.res = X; pc.res_lo = R.lo_in(X); pc.out = Y; pc.out_lo = R.lo_of(Y); pc.ld = d;
+        pc.clip_T = R.clipT;
         R.prof_begin();
         taken = wfl_launch_posconv(pc, R.s);
         R.prof_end(2044, 2.0 * (double)B * p.T * (double)d * (double)cpg * (double)K);
@@ -1625,6 +1680,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
         la.gx = GX; la.ldgx = 8 * Hh; la.whh = m->lstm_whh[layer]; la.out = S; la.ldo = d; la.lead = p.lead;
         la.B = B; la.T = p.T; la.P = p.P; la.H = Hh; la.U = m->lstm_U;
         la.error = (unsigned*)(R.ws + p.err);
+        la.clip_T = R.clipT;
         R.stats_for = nullptr;
         { const int si = R.lo_idx(S); if (si >= 0) R.lo_ok[si] = false; }     // the recurrence writes plain bf16 rows
         R.prof_begin();
@@ -1692,6 +1748,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
     t.rows = B * p.T; t.C = a.num_classes; t.threshold = threshold; t.o_id = a.o_id;
     t.ids = ids; t.argmax = argmax; t.maxprob = maxprob;
     t.hid = S; t.ldh = d; t.lead = p.lead; t.P = p.P; t.T = p.T; t.d = d; t.w2 = m->off_w2; t.b2 = m->off_b2;
+    t.clip_T = R.clipT; t.Tmax = p.T;
     if (n_pass == 1) {
       t.logits = lg; t.ldl = a.num_classes; t.offsets = offsets;
       t.status_src = (const unsigned*)(R.ws + p.err); t.status_dst = status;
@@ -1717,6 +1774,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
         TagArgs f{};
         f.logits = lg; f.ldl = a.num_classes; f.rows = B * p.T; f.C = a.num_classes; f.threshold = threshold;
         f.o_id = a.o_id; f.ids = ids; f.argmax = argmax; f.maxprob = maxprob;
+        f.clip_T = R.clipT; f.Tmax = p.T;
         f.status_src = (const unsigned*)(R.ws + p.err); f.status_dst = status;
         r = wfl_launch_tag_decide(f, R.s);
         if (r) return fail(r, "tag_decide launch failed");

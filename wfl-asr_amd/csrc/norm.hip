@@ -10,7 +10,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                                                         long ldy, const float* __restrict__ gam,
                                                         const float* __restrict__ bet, float eps, long lead, int B, int P,
                                                         int T, int C, const bf16_t* __restrict__ x_lo, bf16_t* __restrict__ y_lo,
-                                                        int n_div) {
+                                                        int n_div, const int* __restrict__ clip_T) {
+  // clip_T: [B] valid frames per clip or null (rows t >= clip_T[b] are left alone)
   // x_lo / y_lo: the low halves of a residual-stream tensor carried as hi + lo (common.h, GemmArgs::res_lo); both optional
   // n_div: channels the statistics are taken over; < C when the row carries zero padding columns (gamma = beta = 0 there: the
   //        `encoder_type: none` head, whose width 80 lives in 128 columns -- model.hip, pad_head_state)
@@ -18,6 +19,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // index over B*T valid rows
   if (r >= (long)B * T) return;
   const int b = (int)(r / T), t = (int)(r - (long)b * T);
+  if (clip_T && t >= clip_T[b]) return;
   const long row = lead + (long)b * P + t;
   const bf16_t* xp = x + row * ldx;
   float v[NCH][8];
@@ -82,29 +84,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 template <bool GELU>
 static int launch_ln(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead, int B,
-                     int P, int T, int C, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo, int n_div) {
+                     int P, int T, int C, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo, int n_div, const int* clip_T) {
   const long rows = (long)B * T;
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (C <= 512)
-    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div);
+    hipLaunchKernelGGL((layernorm_kernel<1, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div, clip_T);
   else if (C <= 1024)
-    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div);
+    hipLaunchKernelGGL((layernorm_kernel<2, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div, clip_T);
   else
-    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div);
+    hipLaunchKernelGGL((layernorm_kernel<4, GELU>), grid, dim3(256), 0, s, x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, x_lo, y_lo, n_div, clip_T);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
-                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo, int n_div) {
+                             int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo, bf16_t* y_lo, int n_div,
+                             const int* clip_T) {
   if (C % 8 || ldx % 8 || ldy % 8 || C > 2048 || n_div < 0 || n_div > C) return -1;
   if (n_div == 0) n_div = C;
-  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo, n_div)
-              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo, n_div);
+  return gelu ? launch_ln<true>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo, n_div, clip_T)
+              : launch_ln<false>(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, s, x_lo, y_lo, n_div, clip_T);
 }
 
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,
                          long lead, int B, int P, int T, int C, hipStream_t s) {
-  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s, nullptr, nullptr, 0);
+  return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s, nullptr, nullptr, 0, nullptr);
 }
 
 // Zero every row that is not a valid frame: [0, lead), each clip's [T, P), and `tail_rows` rows behind the last

@@ -40,6 +40,7 @@ struct PosConvArgs {
   bf16_t* out;                    // y rows (ld), low half (or null)
   bf16_t* out_lo;
   long ld;
+  const int* clip_T;              // [B] valid frames per clip or null
 };
 
 static __device__ __forceinline__ int pc_sswz(int row) { return (-(row >> 2)) & 3; }              // aligned 16-row reads (weights)
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void posconv_kernel(PosConvArgs p) {
     const long m = m0 + wm + 16 * u + c;
     const int t = (int)(m % p.P);
     if (m >= nrows || t >= p.T) continue;
+    if (p.clip_T && t >= p.clip_T[m / p.P]) continue;
     const long row = p.lead + m;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {

@@ -13,9 +13,11 @@
 
 // ---------------------------------------------------------------------------------------------- waveform statistics
 // One workgroup per clip, every partial sum added in a FIXED order (no atomics: the result is bit-identical from run to run)
-__global__ __launch_bounds__(1024) void wav_stats_kernel(const float* __restrict__ wav, long ldw, int L, double* __restrict__ stats) {
+__global__ __launch_bounds__(1024) void wav_stats_kernel(const float* __restrict__ wav, long ldw, int L, double* __restrict__ stats,
+                                                         const int* __restrict__ lens) {
   __shared__ double ps[16], pq[16];
   const int b = blockIdx.x;
+  if (lens) L = lens[b];
   const float* w = wav + (long)b * ldw;
   double s = 0.0, q = 0.0;
   for (long i = threadIdx.x; i < L; i += 1024) {
@@ -42,6 +44,8 @@ struct Conv0Args {
   const float* bias;                      // [C] or null
   const float* gamma; const float* beta;  // [C]
   int B, T0, C;
+  const int* lens;                        // [B] samples per clip or null (= L): statistics, the conv's input range and the frame count
+                                          //   (len - 10) / 5 + 1 follow the clip's own length
   double* cstats;                         // [B][C][2] (group mode)
   float* cpart;                           // [B][time blocks][C][2] per-workgroup partial sums (group mode, pass 1)
   bf16_t* out; long lead; int P;          // frame rows [.., C]
@@ -50,8 +54,9 @@ struct Conv0Args {
 static __device__ __forceinline__ void wav_norm(const Conv0Args& p, int b, float& mean, float& rstd) {
   mean = 0.f; rstd = 1.f;
   if (p.wstats) {
-    const double m = p.wstats[2 * b] / p.L;
-    const double var = p.wstats[2 * b + 1] / p.L - m * m;
+    const int Lb = p.lens ? p.lens[b] : p.L;
+    const double m = p.wstats[2 * b] / Lb;
+    const double var = p.wstats[2 * b + 1] / Lb - m * m;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-7));
   }
@@ -62,13 +67,15 @@ template <bool APPLY>
 __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
   __shared__ float xs[C0_TT * 5 + 16];
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
-  const int nt = min(C0_TT, p.T0 - t0);
+  const int Lb = p.lens ? p.lens[b] : p.L;                      // this clip's samples and level-0 frames
+  const int T0b = p.lens ? (Lb >= 10 ? (Lb - 10) / 5 + 1 : 0) : p.T0;
+  const int nt = max(0, min(C0_TT, T0b - t0));                  // (0: a block beyond a shorter clip's end -- zero partial sums, no output)
   float mean, rstd;
   wav_norm(p, b, mean, rstd);
   const float* w = p.wav + (long)b * p.ldw;
   for (int i = threadIdx.x; i < nt * 5 + 5; i += 256) {
     const long s = (long)t0 * 5 + i;
-    xs[i] = s < p.L ? (w[s] - mean) * rstd : 0.f;
+    xs[i] = s < Lb ? (w[s] - mean) * rstd : 0.f;
   }
   __syncthreads();
   for (int c0 = threadIdx.x * 2; c0 < p.C; c0 += 512) {
@@ -88,8 +95,8 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
       *(f32x4*)st = (f32x4){sa, qa, sb, qb};
     } else {
       const double* st = p.cstats + ((long)b * p.C + c0) * 2;
-      const double ma = st[0] / p.T0, mb = st[2] / p.T0;
-      const double va = st[1] / p.T0 - ma * ma, vb = st[3] / p.T0 - mb * mb;
+      const double ma = st[0] / T0b, mb = st[2] / T0b;
+      const double va = st[1] / T0b - ma * ma, vb = st[3] / T0b - mb * mb;
       const float sca = (float)(1.0 / sqrt((va > 0 ? va : 0) + 1e-5)) * p.gamma[c0];
       const float scb = (float)(1.0 / sqrt((vb > 0 ? vb : 0) + 1e-5)) * p.gamma[c0 + 1];
       const float sha = p.beta[c0] - (float)ma * sca, shb = p.beta[c0 + 1] - (float)mb * scb;
@@ -140,12 +147,14 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args p) {
     bt[e] = p.beta[c];
   }
   const float* w = p.wav + (long)b * p.ldw;
-  for (int t = blockIdx.x * 4 + wid; t < p.T0; t += gridDim.x * 4) {
+  const int Lb = p.lens ? p.lens[b] : p.L;
+  const int T0b = p.lens ? (Lb >= 10 ? (Lb - 10) / 5 + 1 : 0) : p.T0;
+  for (int t = blockIdx.x * 4 + wid; t < T0b; t += gridDim.x * 4) {
     float x[10];
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
       const long s = (long)t * 5 + j;
-      x[j] = s < p.L ? (w[s] - mean) * rstd : 0.f;
+      x[j] = s < Lb ? (w[s] - mean) * rstd : 0.f;
     }
     float y[8], sum = 0.f;
 #pragma unroll
@@ -174,8 +183,8 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args p) {
   }
 }
 
-int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s) {
-  hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(1024), 0, s, wav, ldw, L, stats);
+int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s, const int* lens) {
+  hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(1024), 0, s, wav, ldw, L, stats, lens);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -195,11 +204,34 @@ int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// ---------------------------------------------------------------------------------------------- per-clip frame counts
+// lens[b] samples -> frames of clip b at every level of a conv stack without padding: t <- (t - kernel) / stride + 1 (0 when shorter
+// than the kernel); out[level][b].  One level with kernel 0 / stride hop gives the mel front-end's 1 + len / hop ... (len - 0) / hop + 1.
+struct ClipFramesArgs { const int* lens; int B, L, n; int kernel[8], stride[8]; int min_len; int* out; };
+__global__ void clip_frames_kernel(ClipFramesArgs p) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= p.B) return;
+  long t = min(max(p.lens[b], 0), p.L);
+  if (t < p.min_len) t = -1;                        // too short for the front-end: no frames at any level
+  for (int i = 0; i < p.n; ++i) {
+    t = t >= p.kernel[i] && t >= 0 ? (t - p.kernel[i]) / p.stride[i] + 1 : 0;
+    p.out[i * p.B + b] = (int)t;
+  }
+}
+int wfl_launch_clip_frames(const int* lens, int B, int L, int n, const int* kernel, const int* stride, int min_len, int* out, hipStream_t s) {
+  if (n <= 0 || n > 8 || B <= 0) return -1;
+  ClipFramesArgs a{};
+  a.lens = lens; a.B = B; a.L = L; a.n = n; a.min_len = min_len; a.out = out;
+  for (int i = 0; i < n; ++i) { a.kernel[i] = kernel[i]; a.stride[i] = stride[i]; }
+  hipLaunchKernelGGL(clip_frames_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // ---------------------------------------------------------------------------------------------- positional-conv regroup
 // x [R rows][d] (frame rows) -> xg [groups][R][64]: channels g*cpg .. +cpg of every valid frame, zero elsewhere
 // (padding channels, halo rows): each group's k-tap conv then reads k*64 contiguous elements per frame.
 __global__ __launch_bounds__(256) void regroup_kernel(const bf16_t* __restrict__ x, int d, int groups, int cpg, long R, long lead,
-                                                      int B, int P, int T, bf16_t* __restrict__ xg) {
+                                                      int B, int P, int T, bf16_t* __restrict__ xg, const int* __restrict__ clip_T) {
   const long total = (long)groups * R * 8;     // 16-byte chunks
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ch = (int)(i & 7);
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(256) void regroup_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
     const long k = r - lead;
-    if (k >= 0 && k < (long)B * P && (k % P) < T) {
+    if (k >= 0 && k < (long)B * P && (k % P) < (clip_T ? clip_T[k / P] : T)) {
       const int c0 = ch * 8;
       if (c0 + 8 <= cpg) v = *(const bf16x8*)(x + r * d + g * cpg + c0);
       else if (c0 < cpg) {
@@ -222,12 +254,13 @@ __global__ __launch_bounds__(256) void regroup_kernel(const bf16_t* __restrict__
   }
 }
 
-int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s) {
+int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s,
+                       const int* clip_T) {
   if (cpg > 64 || cpg % 8 || (cpg * groups) != d) return -1;
   const long total = (long)groups * R * 8;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, d, groups, cpg, R, lead, B, P, T, xg);
+  hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, d, groups, cpg, R, lead, B, P, T, xg, clip_T);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

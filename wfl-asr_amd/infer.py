@@ -178,15 +178,28 @@ class Labeler:
             finish(1)
 
     def _forward_items_by_length(self, items, lang_id, threshold):
-        """WavLM: the frame count follows the clip length and the reference never pads WavLM input (padding would change the
-        GroupNorm statistics and the unmasked attention), so a batch holds rows of exactly equal length.  Same pipeline as
-        `_run_batches`: two batches in flight on two streams / workspace slots, pinned staging both ways, the status word read
-        with the tags."""
+        """WavLM and the mel front-end: the frame count follows the clip length and the reference never pads their input (padding
+        would change the waveform / GroupNorm statistics, the unmasked attention and where the backward LSTM starts).  A batch may
+        still hold clips of different lengths: the library takes per-clip sample counts (`lens`) and carries every clip's own frame
+        count through the whole forward, so each row comes out as if labelled alone (csrc/model.hip, Runner::clipT).  Clips are
+        sorted by length so that a batch wastes little on its shorter rows; `WFL_RAGGED=0` goes back to one length per batch.
+        Same pipeline as `_run_batches`: two batches in flight on two streams / workspace slots, pinned staging both ways, the
+        status word read with the tags."""
         out = [None] * len(items)
-        by_len = {}
-        for i, x in enumerate(items):
-            by_len.setdefault(len(x), []).append(i)
-        jobs = [(n, idxs[s:s + self.batch_size]) for n, idxs in by_len.items() for s in range(0, len(idxs), self.batch_size)]
+        Bs = self.batch_size
+        ragged = os.environ.get("WFL_RAGGED", "1") != "0"
+        frames = [self.model.num_frames(len(x)) for x in items]
+        for i, t in enumerate(frames):
+            if t <= 0:
+                raise ValueError(f"clip {i} is too short for the {self.model.encoder_type} front-end ({len(items[i])} samples)")
+        if ragged:
+            order = sorted(range(len(items)), key=lambda i: -len(items[i]))
+            jobs = [order[s:s + Bs] for s in range(0, len(order), Bs)]
+        else:
+            by_len = {}
+            for i, x in enumerate(items):
+                by_len.setdefault(len(x), []).append(i)
+            jobs = [idxs[s:s + Bs] for n, idxs in by_len.items() for s in range(0, len(idxs), Bs)]
         if self._streams is None:
             self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         pending = [None, None]
@@ -204,12 +217,14 @@ class Labeler:
             ids = blob[0:nn].reshape(len(sel), T)
             offs = blob[2 * nn:4 * nn].view(np.float32).reshape(len(sel), T, 2)
             for j, i in enumerate(sel):
-                out[i] = (ids[j].copy(), offs[j].copy())
+                out[i] = (ids[j, :frames[i]].copy(), offs[j, :frames[i]].copy())
             pending[slot] = None
 
-        for k, (n, sel) in enumerate(jobs):
+        for k, sel in enumerate(jobs):
             slot = k % 2
             finish(slot)
+            n = max(len(items[i]) for i in sel)
+            same = all(len(items[i]) == n for i in sel)
             T = self.model.num_frames(n)
             need_in, need_out = len(sel) * n, len(sel) * T * 4 + 1
             if pin_in[slot] is None or pin_in[slot].numel() < need_in:
@@ -218,10 +233,11 @@ class Labeler:
                 pin_out[slot] = torch.empty(need_out, dtype=torch.int32).pin_memory()
             host = pin_in[slot][:need_in].view(len(sel), n)
             for j, i in enumerate(sel):
-                host[j] = torch.from_numpy(np.ascontiguousarray(items[i]))
+                host[j, :len(items[i])] = torch.from_numpy(np.ascontiguousarray(items[i]))
+            lens = None if same else np.array([len(items[i]) for i in sel], np.int32)
             with torch.cuda.stream(self._streams[slot]):
                 wav = host.to(self.device, non_blocking=True)
-                res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold,
+                res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold, lens=lens,
                                        average_languages=lang_id is None, slot=slot)
                 pin_out[slot][:need_out].copy_(res.packed, non_blocking=True)
                 ev = torch.cuda.Event()

@@ -239,6 +239,8 @@ class BIOPhonemeTagger:
             lang_d = lang_t.to(dev).contiguous() if lang_t is not None else None
             lens_d = lens_t.to(dev).contiguous() if lens_t is not None else None
             out = self._alloc_out(B, T, dev, want_logits, want_hidden)
+            if lens_d is not None and out.logits is not None and self.encoder_type != "whisper":
+                out.logits.zero_()             # (frames behind a shorter clip's own count are not written by the forward)
             self._launch(x, lens_d, lang_d, mode, threshold, out, slot)
             return out
         # one graph per signature AND workspace slot: a graph owns static inputs/outputs and replays on its slot's workspace,
