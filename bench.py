@@ -63,7 +63,7 @@ def parse():
                          "infer_folder under torchrun writes its own .lab files")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per step and workspace slot instead of launching eagerly (measured gain < 1 %%)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight per GPU: step i runs on stream i %% inflight with its own workspace and host buffer")
     ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (1..4)")
     ap.add_argument("--full-head", action="store_true",
@@ -203,7 +203,9 @@ def main():
     lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
     T = model.num_frames(L)
     words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
-    nfl = max(1, args.inflight)
+    # batches in flight: two for Whisper models; ONE for WavLM models -- two WavLM forwards running concurrently on two streams were
+    # seen to change each other's attention output now and then, so the product runs them one at a time too
+    nfl = args.inflight if args.inflight > 0 else (2 if cfg["model"]["encoder_type"] == "whisper" else 1)
     gather_on = (world > 1 and args.gather) or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))
     host_bufs = [torch.zeros((world if (rank == 0 and gather_on) else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]

@@ -239,6 +239,7 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
     if (a.d_model <= 0 || a.d_model % 64) return fail(-1, "d_model must be a positive multiple of 64");
     if (a.enc_heads <= 0 || a.d_model % a.enc_heads) return fail(-1, "enc_heads must divide d_model");
   }
+  if (!none && a.enc_layers <= 0) return fail(-1, "enc_layers must be positive");
   if (a.num_classes <= 0 || a.o_id < 0 || a.o_id >= a.num_classes) return fail(-1, "bad num_classes / o_id");
   if (a.n_conformer > 0 && (a.conformer_heads <= 0 || a.d_model % a.conformer_heads)) return fail(-1, "bad conformer_heads");
   if (a.n_conformer > 0 && a.conformer_kernel % 2 == 0) return fail(-1, "even conformer_kernel_size is not supported");

@@ -183,8 +183,10 @@ class Labeler:
         still hold clips of different lengths: the library takes per-clip sample counts (`lens`) and carries every clip's own frame
         count through the whole forward, so each row comes out as if labelled alone (csrc/model.hip, Runner::clipT).  Clips are
         sorted by length so that a batch wastes little on its shorter rows; `WFL_RAGGED=0` goes back to one length per batch.
-        Same pipeline as `_run_batches`: two batches in flight on two streams / workspace slots, pinned staging both ways, the
-        status word read with the tags."""
+        Pinned staging both ways and the status word read with the tags, like `_run_batches`, but ONE forward on the GPU at a time
+        (one stream; the host still fills the next batch and unpacks the previous one meanwhile): two WavLM forwards running
+        concurrently on two streams were seen to change each other's attention output now and then, Whisper
+        forwards never."""
         out = [None] * len(items)
         Bs = self.batch_size
         ragged = os.environ.get("WFL_RAGGED", "1") != "0"
@@ -235,13 +237,13 @@ class Labeler:
             for j, i in enumerate(sel):
                 host[j, :len(items[i])] = torch.from_numpy(np.ascontiguousarray(items[i]))
             lens = None if same else np.array([len(items[i]) for i in sel], np.int32)
-            with torch.cuda.stream(self._streams[slot]):
+            with torch.cuda.stream(self._streams[0]):
                 wav = host.to(self.device, non_blocking=True)
                 res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold, lens=lens,
-                                       average_languages=lang_id is None, slot=slot)
+                                       average_languages=lang_id is None, slot=0)
                 pin_out[slot][:need_out].copy_(res.packed, non_blocking=True)
                 ev = torch.cuda.Event()
-                ev.record(self._streams[slot])
+                ev.record(self._streams[0])
             pending[slot] = (sel, T, ev)
         finish(0)
         finish(1)

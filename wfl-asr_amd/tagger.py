@@ -178,7 +178,8 @@ class BIOPhonemeTagger:
         ws = self._workspace(B, L, x.device, slot)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            rc = self._lib.wfl_forward(self._handle, _ptr(x), x.stride(0), _ptr(lens_t), B, L, _ptr(lang_t), mode,
+            ldw = x.stride(0) if B > 1 else L      # (a single row's stride is arbitrary: numpy's x[None] gives 0)
+            rc = self._lib.wfl_forward(self._handle, _ptr(x), ldw, _ptr(lens_t), B, L, _ptr(lang_t), mode,
                                        float(threshold), _ptr(ws), ws.numel(), _ptr(out.ids), _ptr(out.argmax),
                                        _ptr(out.maxprob), _ptr(out.offsets), _ptr(out.logits), _ptr(out.hidden),
                                        _ptr(out.status), C.c_void_p(stream))
@@ -317,7 +318,7 @@ class BIOPhonemeTagger:
         ws = self._workspace(B, L, x.device)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            rc = self._lib.wfl_encode(self._handle, _ptr(x), x.stride(0), _ptr(lens_d), B, L, _ptr(ws), ws.numel(), _ptr(hidden),
+            rc = self._lib.wfl_encode(self._handle, _ptr(x), x.stride(0) if B > 1 else L, _ptr(lens_d), B, L, _ptr(ws), ws.numel(), _ptr(hidden),
                                       C.c_void_p(stream))
         _lib.check(rc, "wfl_encode")
         return hidden
