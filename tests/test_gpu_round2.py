@@ -413,3 +413,24 @@ def test_clips_of_different_lengths_in_one_batch_equal_the_clips_labelled_alone(
         assert torch.equal(out.ids[b, :Tb], one.ids[0]) and torch.equal(out.offsets[b, :Tb], one.offsets[0])
         assert bool((out.ids[b, Tb:] == m.label2id["O"]).all()) and bool((out.maxprob[b, Tb:] == 0).all())
     m.check(B, L)
+
+
+def test_two_whisper_forwards_in_flight_do_not_disturb_each_other_at_batch_1():
+    """Single-clip Whisper-base forwards (small grids: the kernels of two forwards really share the GPU) alternating on two streams /
+    workspace slots equal the single-stream results bit for bit.  (The product keeps two Whisper batches in flight; WavLM / mel
+    forwards run one at a time: DESIGN.md section 7, tools/repro_wavlm_two_streams.py.)"""
+    cfg = synth.baseline_config(1)
+    m, labels, _ = _build(cfg, 70, seed=72)
+    base = synth.make_clip(7100, 480000, seed=72) * 0.8
+    items = [torch.from_numpy(np.ascontiguousarray(np.roll(base, 997 * i)[None]).astype(np.float32)).cuda() for i in range(12)]
+    ref = [m.label(x, [i % 2], threshold=0.5, want_logits=True) for i, x in enumerate(items)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = []
+        for k, x in enumerate(items):
+            with torch.cuda.stream(streams[k % 2]):
+                outs.append(m.label(x, [k % 2], threshold=0.5, want_logits=True, slot=k % 2))
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets), (rep, k)
