@@ -203,9 +203,7 @@ def main():
     lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
     T = model.num_frames(L)
     words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
-    # batches in flight: two for Whisper models; ONE for WavLM models -- two WavLM forwards running concurrently on two streams were
-    # seen to change each other's attention output now and then, so the product runs them one at a time too
-    nfl = args.inflight if args.inflight > 0 else (2 if cfg["model"]["encoder_type"] == "whisper" else 1)
+    nfl = args.inflight if args.inflight > 0 else 2         # batches in flight (the product's loops keep two)
     gather_on = (world > 1 and args.gather) or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))
     host_bufs = [torch.zeros((world if (rank == 0 and gather_on) else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]

@@ -434,3 +434,26 @@ def test_two_whisper_forwards_in_flight_do_not_disturb_each_other_at_batch_1():
         torch.cuda.synchronize()
         for k, o in enumerate(outs):
             assert torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets), (rep, k)
+
+
+def test_two_wavlm_forwards_in_flight_do_not_disturb_each_other():
+    """WavLM-base (group-norm feature encoder, 12 layers), single clips of different lengths alternating on two streams / workspace
+    slots: bit-identical to the single-stream results.  Before conv0's group-norm kernel was given its CUs to itself (wavlm.hip) a
+    quarter of such forwards came out different while another forward's attention workgroups shared their CUs."""
+    cfg = synth.baseline_config(0)
+    m, labels, _ = _build(cfg, 70, seed=73)
+    rng = np.random.default_rng(3)
+    base = synth.make_clip(7200, 160000, seed=73) * 0.8
+    items = [torch.from_numpy(np.ascontiguousarray(np.roll(base, 997 * i)[:int(rng.integers(32000, 160000))]).astype(np.float32)[None]).cuda()
+             for i in range(24)]
+    ref = [m.label(x, [0], threshold=0.5, want_logits=True) for x in items]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(4):
+        outs = []
+        for k, x in enumerate(items):
+            with torch.cuda.stream(streams[k % 2]):
+                outs.append(m.label(x, [0], threshold=0.5, want_logits=True, slot=k % 2))
+        torch.cuda.synchronize()
+        bad = [k for k, o in enumerate(outs) if not (torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets))]
+        assert not bad, (rep, bad)

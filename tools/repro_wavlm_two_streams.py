@@ -1,13 +1,10 @@
 #!/usr/bin/env python3
-"""Diagnostic (not product), OPEN ISSUE: two WavLM forwards running concurrently on two HIP streams (different model instances,
-different workspaces) now and then change each other's result -- the encoder output of a WavLM-base forward differs from its
-single-stream value in 15-40 % of the runs while another WavLM-base forward runs beside it; the same forwards alternating on ONE
-stream are bit-exact.  Established so far (round 2): the first differences already show in the feature encoder
-(a small chance per kernel that grows along the forward, not one faulty kernel); the attention and GEMM kernels are bit-exact under
-the same concurrency when driven directly through wfl_op_* (also with the producer -> consumer chain and large scores); no forward
-writes outside its workspace (guard bands) or reads stale workspace contents (poisoned workspaces); Whisper forwards (B = 1 and
-B = 16, eager and graph replay) do not show it; a neighbour that stops before its own attention does not disturb.  Mitigation in the product: WavLM / mel models keep ONE forward on the GPU at a
-time (infer.py:_forward_items_by_length, bench.py --inflight default).  usage: repro_wavlm_two_streams.py"""
+"""Diagnostic (not product): a WavLM-base encoder forward on one HIP stream beside other WavLM-base forwards on a second stream
+(another model instance, separate workspaces), compared bit for bit with its single-stream result; and the same two forwards
+alternating on ONE stream.  Round 2 found 15-40 % of the two-stream runs different: conv0's group-norm kernel produced wrong rows
+when its workgroups shared a CU with another forward's prefetching-attention workgroups (mechanism not understood; DESIGN.md
+section 7).  With conv0 given its CUs to itself (wavlm.hip; WFL_CONV0_LDS_PAD=0 undoes it) both lines read 0 of 96.
+usage: repro_wavlm_two_streams.py"""
 import os, sys, dataclasses
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

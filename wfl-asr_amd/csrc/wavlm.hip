@@ -193,9 +193,23 @@ int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s) {
   if (group_norm) {
     if (!a.cpart) return -1;
     dim3 grid((a.T0 + C0_TT - 1) / C0_TT, a.B);
-    hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), 0, s, a);
+    // The two conv0 passes ask for 136 KiB of dynamic LDS they never touch, so that no other workgroup shares their CU.  Found in
+    // round 2: a conv0_group workgroup that shares a CU with workgroups of the prefetching attention kernels (another forward on
+    // another stream) now and then produces wrong rows -- 14-18 of 96 WavLM-base forwards differed, none with a CU of its own
+    // (the mechanism is not understood: neither kernel leaves its LDS allocation).  WFL_CONV0_LDS_PAD=0 removes
+    // the padding.
+    static int pad = -1;
+    static WflOncePerDevice attr_once;
+    if (pad < 0) { const char* e = getenv("WFL_CONV0_LDS_PAD"); pad = e ? atoi(e) : 136 * 1024; }
+    if (pad > 0 && attr_once.need()) {
+      if (hipFuncSetAttribute((const void*)conv0_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad) != hipSuccess ||
+          hipFuncSetAttribute((const void*)conv0_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad) != hipSuccess)
+        return -2;
+    }
+    const int dbg_lds = pad;
+    hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), dbg_lds, s, a);
     hipLaunchKernelGGL(conv0_stats_reduce_kernel, dim3((a.C + 255) / 256, a.B), dim3(256), 0, s, a.cpart, (int)grid.x, a.C, a.cstats);
-    hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), dbg_lds, s, a);
   } else {
     int bx = (a.T0 + 3) / 4;
     if (bx > 2048) bx = 2048;

@@ -183,10 +183,10 @@ class Labeler:
         still hold clips of different lengths: the library takes per-clip sample counts (`lens`) and carries every clip's own frame
         count through the whole forward, so each row comes out as if labelled alone (csrc/model.hip, Runner::clipT).  Clips are
         sorted by length so that a batch wastes little on its shorter rows; `WFL_RAGGED=0` goes back to one length per batch.
-        Pinned staging both ways and the status word read with the tags, like `_run_batches`, but ONE forward on the GPU at a time
-        (one stream; the host still fills the next batch and unpacks the previous one meanwhile): two WavLM forwards running
-        concurrently on two streams were seen to change each other's attention output now and then, Whisper
-        forwards never."""
+        Same pipeline as `_run_batches`: two batches in flight on two streams / workspace slots, pinned staging both ways, the
+        status word read with the tags.  (Two WavLM-base forwards in flight used to disturb each other now and then: the group-norm
+        conv0 kernel, sharing a CU with another forward's attention workgroups -- it now keeps its CUs to itself, DESIGN.md
+        section 7; `test_two_wavlm_forwards_in_flight_do_not_disturb_each_other` guards it.)"""
         out = [None] * len(items)
         Bs = self.batch_size
         ragged = os.environ.get("WFL_RAGGED", "1") != "0"
@@ -237,13 +237,13 @@ class Labeler:
             for j, i in enumerate(sel):
                 host[j, :len(items[i])] = torch.from_numpy(np.ascontiguousarray(items[i]))
             lens = None if same else np.array([len(items[i]) for i in sel], np.int32)
-            with torch.cuda.stream(self._streams[0]):
+            with torch.cuda.stream(self._streams[slot]):
                 wav = host.to(self.device, non_blocking=True)
                 res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold, lens=lens,
-                                       average_languages=lang_id is None, slot=0)
+                                       average_languages=lang_id is None, slot=slot)
                 pin_out[slot][:need_out].copy_(res.packed, non_blocking=True)
                 ev = torch.cuda.Event()
-                ev.record(self._streams[0])
+                ev.record(self._streams[slot])
             pending[slot] = (sel, T, ev)
         finish(0)
         finish(1)
