@@ -457,3 +457,26 @@ def test_two_wavlm_forwards_in_flight_do_not_disturb_each_other():
         torch.cuda.synchronize()
         bad = [k for k, o in enumerate(outs) if not (torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets))]
         assert not bad, (rep, bad)
+
+
+def test_two_default_head_forwards_in_flight_do_not_disturb_each_other():
+    """Whisper-base + the default head (2-layer BiLSTM, 2 Conformer blocks, dilated stack), pairs of clips alternating on two streams /
+    workspace slots: the recurrence's workgroups (register-resident weights, LDS fragment images, loader wave) share the GPU with the
+    other forward's GEMM / attention workgroups; results equal the single-stream ones bit for bit and no hand-off times out."""
+    cfg = synth.base_config("whisper")
+    m, labels, _ = _build(cfg, 40, seed=74)
+    base = synth.make_clip(7300, 480000, seed=74) * 0.8
+    items = [torch.from_numpy(np.ascontiguousarray(np.stack([np.roll(base, 997 * i), np.roll(base, 131 * i + 7)])).astype(np.float32)).cuda()
+             for i in range(8)]
+    ref = [m.label(x, [0, 1], threshold=0.5, want_logits=True) for x in items]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = []
+        for k, x in enumerate(items):
+            with torch.cuda.stream(streams[k % 2]):
+                outs.append(m.label(x, [0, 1], threshold=0.5, want_logits=True, slot=k % 2))
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert int(o.status.item()) == 0
+            assert torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets), (rep, k)
