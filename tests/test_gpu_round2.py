@@ -480,3 +480,33 @@ def test_two_default_head_forwards_in_flight_do_not_disturb_each_other():
         for k, o in enumerate(outs):
             assert int(o.status.item()) == 0
             assert torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets), (rep, k)
+
+
+@pytest.mark.parametrize("kind", ["mel", "wavlm_large_bilstm"])
+def test_two_forwards_in_flight_other_front_ends(kind):
+    """The same two-streams check for the mel front-end (default head at width 80) and for WavLM-large geometry (layer-norm feature
+    encoder, stable layer norm, 2 layers, BiLSTM hidden 512 + dilated stack), clips of different lengths."""
+    import dataclasses
+    from wfl_asr_amd.archs import WAVLM
+    if kind == "mel":
+        cfg, scale = synth.base_config("none"), 0.05
+    else:
+        cfg, scale = synth.baseline_config(2), 0.8
+        a = dataclasses.asdict(WAVLM["large"]); a["layers"] = 2
+        cfg["model"]["wavlm_model"] = "local/wavlm-large-2l"; cfg["model"]["encoder_arch"] = a
+    m, labels, _ = _build(cfg, 30, seed=75)
+    rng = np.random.default_rng(5)
+    base = synth.make_clip(7400, 160000, seed=75) * scale
+    items = [torch.from_numpy(np.ascontiguousarray(np.roll(base, 997 * i)[:int(rng.integers(32000, 160000))]).astype(np.float32)[None]).cuda()
+             for i in range(16)]
+    ref = [m.label(x, [0], threshold=0.5, want_logits=True) for x in items]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = []
+        for k, x in enumerate(items):
+            with torch.cuda.stream(streams[k % 2]):
+                outs.append(m.label(x, [0], threshold=0.5, want_logits=True, slot=k % 2))
+        torch.cuda.synchronize()
+        bad = [k for k, o in enumerate(outs) if not (torch.equal(o.logits, ref[k].logits) and torch.equal(o.offsets, ref[k].offsets))]
+        assert not bad, (kind, rep, bad)
