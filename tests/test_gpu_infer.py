@@ -118,3 +118,21 @@ def test_forced_alignment_and_cli(workdir):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "infer.py"), str(d / "wavs"), "-ckpt", ck, "-c", cp, "-s"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "neither --top-k nor --top-p" in r.stdout
+
+
+def test_bench_emits_one_json_line_with_the_contract_keys():
+    """bench.py is what the driver times: a short run must print exactly one JSON line with the contract's keys (roofline and
+    cpu_baseline objects included) and a status-clean forward."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-calls", "1", "--cpu-clips", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 3 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert "workload" in d["config"]
