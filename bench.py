@@ -10,8 +10,9 @@ Default workload = BASELINE.json configs[1]: Whisper-base + 2 Conformer blocks, 
 the clips are independent, ranks share nothing but the final gather).  `--config-index 2|3|4` selects the other BASELINE
 configs at their per-GPU sizes (64 x 10 s WavLM-large + BiLSTM + dilated; 64 x 30 s Whisper-small + full head; 32 x 30 s
 Whisper-large-v3), `--full-head` the reference's default config.yaml head on Whisper-base.  Steps alternate between `--inflight`
-(default 2) HIP streams, each with its own workspace and pinned host buffer, so two batches are in flight per GPU (every step
-is still a complete pass over its own batch, and all K steps are inside the timed, fenced region).
+HIP streams (default: what the product's labelling loops keep -- 2, or 3 with `--full-head`, tagger.batches_in_flight), each with
+its own workspace and pinned host buffer, so that many batches are in flight per GPU (every step is still a complete pass over its
+own batch, and all K steps are inside the timed, fenced region).
 
 Besides the contract fields the JSON line carries
   roofline        the dominant kernel family (bf16 MFMA GEMMs): algorithmic FLOPs / HIP-event time per launch, measured on the
@@ -203,7 +204,8 @@ def main():
     lang = (torch.arange(B, device=dev) % cfg["model"]["num_languages"]).to(torch.int32)
     T = model.num_frames(L)
     words = B * T * 4 + 1                                 # one rank's packed tags: ids | max-prob | offsets | status word
-    nfl = args.inflight if args.inflight > 0 else 2         # batches in flight (the product's loops keep two)
+    nfl = args.inflight if args.inflight > 0 else model.batches_in_flight()   # what the product's loops keep: 2, or 3 for a BiLSTM
+                                                                              # behind a small encoder (tagger.batches_in_flight)
     gather_on = (world > 1 and args.gather) or bool(os.environ.get("WFL_BENCH_FAKE_WORLD"))
     host_bufs = [torch.zeros((world if (rank == 0 and gather_on) else 1), words, dtype=torch.int32).pin_memory() for _ in range(nfl)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nfl - 1)]
@@ -247,6 +249,12 @@ def main():
             for r in range(hb.shape[0]):
                 raise_on_status(int(hb[r, words - 1]))
 
+    # setup, not steps: every slot's workspace, stream and pinned buffer exists before the W warm-up steps (W may be smaller than
+    # the number of slots; a slot first touched inside the timed region would put its workspace allocation there)
+    for _ in range(nfl):
+        step()
+    fence()
+    step_no[0] = 0
     for _ in range(args.warmup):
         step()
     fence()

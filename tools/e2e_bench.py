@@ -25,9 +25,11 @@ from wfl_asr_amd import synth
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--files", type=int, default=96)
+    ap.add_argument("--full-head", action="store_true", help="the default config.yaml head (BiLSTM + Conformer + dilated) at the "
+                    "Labeler's own batch size and batches in flight; prints the end-to-end rate only")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="wfl_e2e_")
-    cfg = synth.baseline_config(1)
+    cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(1)
     cfg["output"] = {"save_dir": os.path.join(d, "save")}
     cfg["postprocess"] = {"median_filter": 3, "merge_segments": "right", "confidence_threshold": 0.5}
     cfg.setdefault("data", {})["sample_rate"] = 16000
@@ -46,9 +48,17 @@ def main():
         p = os.path.join(wavs, f"{i:04d}.wav")
         A.write_wav(p, base[i % 8], 16000)
         paths.append(p)
-    lab = I.Labeler(cfg, sd, "cuda", batch_size=16)
-    lab.label_files(paths[:16], lang_id=0, confidence_threshold=0.5, verbose=False)      # warm-up
+    lab = I.Labeler(cfg, sd, "cuda", batch_size=None if args.full_head else 16)
+    lab.label_files(paths[:4 * lab.batch_size], lang_id=0, confidence_threshold=0.5, verbose=False)      # warm-up
     torch.cuda.synchronize()
+    if args.full_head:
+        t0 = time.perf_counter()
+        out = lab.label_files(paths, lang_id=0, confidence_threshold=0.5, verbose=False)
+        t_all = time.perf_counter() - t0
+        n = len(paths)
+        print(f"default config.yaml head | files {n} x 30 s | rows per forward {lab.batch_size}, batches in flight {lab.n_inflight} | "
+              f"label_files end to end {1e3 * t_all / n:.2f} ms/file = {30 * n / t_all:.0f} audio-s/s; segments/file {np.mean([len(o) for o in out]):.0f}")
+        return
 
     t0 = time.perf_counter()
     clips = [A.load_clip(p, 16000) for p in paths]

@@ -11,8 +11,8 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py"
 echo "== bench lines"
 timeout -k 10 400 $B > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err || exit 1
-timeout -k 10 300 $B --full-head --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_fullhead_b16.json 2>> $OUT/bench.err || exit 1
-timeout -k 10 300 $B --full-head --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_fullhead_b64.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 $B --full-head --steps 24 --warmup 3 --no-cpu-baseline > $OUT/bench_fullhead_b16.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 $B --full-head --batch 64 --steps 12 --warmup 3 --no-cpu-baseline > $OUT/bench_fullhead_b64.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 $B --config-index 2 --steps 6 --warmup 2 --cpu-clips 2 --cpu-calls 3 > $OUT/bench_cfg3.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 $B --config-index 3 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg4.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 $B --config-index 4 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_fp8.json 2>> $OUT/bench.err || exit 1
@@ -29,6 +29,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wri
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B $P4 > $OUT/pmc_sq.log 2>&1 || exit 1
 echo "== files -> .lab end to end"
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 2> /dev/null | tail -1 > $OUT/e2e_label_files.txt || exit 1
+timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --full-head --files 768 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
 echo "== lstm micro"
 (cd $ROOT/tools/micro && ./lstm_bench_stamps > $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 512 64 499 >> $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 384 64 1500 >> $OUT/lstm_step_breakdown.txt 2>&1)
 find $OUT -name "*.csv" | head -30

@@ -79,12 +79,13 @@ class Labeler:
             self.model.set_average_languages(list(self.lang2id.values()))
         if batch_size is None:
             # rows per forward.  A BiLSTM's recurrence costs the same ~1.2 us per time step for 16 clips as for 64 (clips run in
-            # groups of 16 on their own workgroups), so wide batches amortise it: default head, 64 rows 96 k audio-s/s, 16 rows 70 k
+            # groups of 16 on their own workgroups), so wide batches amortise it: default head, 64 rows 105 k audio-s/s, 16 rows 83 k
             # (DESIGN.md section 5).  A clip's tags do not depend on what shares its batch (bit-exact batch invariance).
             batch_size = int(os.environ.get("WFL_BATCH_SIZE", "64" if self.model.head_cfg["enable_bilstm"] else "16"))
         self.batch_size = int(batch_size)
         self.use_graph = bool(use_graph)
         self._pinned = None
+        self.n_inflight = self.model.batches_in_flight()   # batches on the GPU at once: stream + workspace slot each
         self._table = npost.LabelTable(self.labels)          # native BIO decode works on ids (csrc/hostpost.hip)
         self._streams = None
 
@@ -114,23 +115,25 @@ class Labeler:
         return out
 
     def _run_batches(self, n_batches, fill, take, lang_id, threshold):
-        """The pipelined hot loop.  Two batches in flight on the GPU (stream and workspace slot k % 2, own pinned output buffer),
-        a third one being filled: `fill(k, pinned_rows) -> (lens, rows used)` runs on a worker thread one batch ahead of the
-        launches (the native loader releases the GIL), into a ring of three pinned input buffers, each guarded by the event of its
-        last host-to-device copy; the main thread launches batch k and unpacks batch k - 2 (`take(k, rows, ids[B, T],
-        offsets[B, T, 2])`, views into pinned memory: copy what you keep).  With everything on one thread (round 2's first half)
+        """The pipelined hot loop.  NS = `n_inflight` batches in flight on the GPU (two, or three for a BiLSTM behind a small
+        encoder -- tagger.batches_in_flight; stream and workspace slot k % NS, own pinned output buffer), one more being filled:
+        `fill(k, pinned_rows) -> (lens, rows used)` runs on a worker thread one batch ahead of the launches (the native loader
+        releases the GIL), into a ring of NS + 1 pinned input buffers, each guarded by the event of its last host-to-device
+        copy; the main thread launches batch k and unpacks batch k - NS (`take(k, rows, ids[B, T], offsets[B, T, 2])`, views
+        into pinned memory: copy what you keep).  With everything on one thread (round 2's first half)
         the end-to-end rate of a folder of 30 s files was 82 k audio-s/s against 123 k for batches already resident."""
         from concurrent.futures import ThreadPoolExecutor
         Bs = self.batch_size
         L = CHUNK_SAMPLES
         T = self.model.num_frames(L)
-        NI = 3
+        NS = self.n_inflight
+        NI = NS + 1
         if self._pinned is None or len(self._pinned) != NI or self._pinned[0].shape[0] != Bs:
             self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(NI)]
-            self._pinned_out = [torch.empty(Bs * T * 4 + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
+            self._pinned_out = [torch.empty(Bs * T * 4 + 1, dtype=torch.int32).pin_memory() for _ in range(NS)]
+        self._ensure_streams()
         use_pipe = not self.use_graph
-        pending = [None, None]
+        pending = [None] * NS
         copied = [None] * NI                               # event behind the last H2D copy out of input buffer i
 
         def finish(slot):
@@ -148,7 +151,7 @@ class Labeler:
         def fill_job(k):
             ib = k % NI
             if copied[ib] is not None:
-                copied[ib].synchronize()                   # (three batches back: long done)
+                copied[ib].synchronize()                   # (NS + 1 batches back: long done)
             return fill(k, self._pinned[ib])
 
         if n_batches <= 0:
@@ -159,7 +162,7 @@ class Labeler:
                 lens, n = fut.result()
                 if k + 1 < n_batches:
                     fut = pool.submit(fill_job, k + 1)
-                slot = k % 2 if use_pipe else 0
+                slot = k % NS if use_pipe else 0
                 finish(slot)                               # the output buffer and workspace of this slot are free again
                 host = self._pinned[k % NI]
                 stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
@@ -174,8 +177,12 @@ class Labeler:
                     ev = torch.cuda.Event()
                     ev.record(stream)
                 pending[slot] = (k, n, ev)
-            finish(0)
-            finish(1)
+            for k in range(max(0, n_batches - NS), n_batches):   # what is still in flight, oldest first
+                finish(k % NS if use_pipe else 0)
+
+    def _ensure_streams(self):
+        if self._streams is None or len(self._streams) != self.n_inflight:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(self.n_inflight)]
 
     def _forward_items_by_length(self, items, lang_id, threshold):
         """WavLM and the mel front-end: the frame count follows the clip length and the reference never pads their input (padding
@@ -183,7 +190,7 @@ class Labeler:
         still hold clips of different lengths: the library takes per-clip sample counts (`lens`) and carries every clip's own frame
         count through the whole forward, so each row comes out as if labelled alone (csrc/model.hip, Runner::clipT).  Clips are
         sorted by length so that a batch wastes little on its shorter rows; `WFL_RAGGED=0` goes back to one length per batch.
-        Same pipeline as `_run_batches`: two batches in flight on two streams / workspace slots, pinned staging both ways, the
+        Same pipeline as `_run_batches`: `n_inflight` batches in flight on their streams / workspace slots, pinned staging both ways, the
         status word read with the tags.  (Two WavLM-base forwards in flight used to disturb each other now and then: the group-norm
         conv0 kernel, sharing a CU with another forward's attention workgroups -- it now keeps its CUs to itself, DESIGN.md
         section 7; `test_two_wavlm_forwards_in_flight_do_not_disturb_each_other` guards it.)"""
@@ -202,10 +209,10 @@ class Labeler:
             for i, x in enumerate(items):
                 by_len.setdefault(len(x), []).append(i)
             jobs = [idxs[s:s + Bs] for n, idxs in by_len.items() for s in range(0, len(idxs), Bs)]
-        if self._streams is None:
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
-        pending = [None, None]
-        pin_in, pin_out = [None, None], [None, None]
+        self._ensure_streams()
+        NS = self.n_inflight
+        pending = [None] * NS
+        pin_in, pin_out = [None] * NS, [None] * NS
 
         def finish(slot):
             job = pending[slot]
@@ -223,7 +230,7 @@ class Labeler:
             pending[slot] = None
 
         for k, sel in enumerate(jobs):
-            slot = k % 2
+            slot = k % NS
             finish(slot)
             n = max(len(items[i]) for i in sel)
             same = all(len(items[i]) == n for i in sel)
@@ -245,8 +252,8 @@ class Labeler:
                 ev = torch.cuda.Event()
                 ev.record(self._streams[slot])
             pending[slot] = (sel, T, ev)
-        finish(0)
-        finish(1)
+        for k in range(max(0, len(jobs) - NS), len(jobs)):
+            finish(k % NS)
         return out
 
     def _lang_name(self, lang_id):

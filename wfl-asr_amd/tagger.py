@@ -8,6 +8,7 @@ current HIP stream.  PyTorch is used only for device buffers and the stream hand
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -139,6 +140,18 @@ class BIOPhonemeTagger:
 
     def num_frames(self, L: int) -> int:
         return int(self._lib.wfl_num_frames(self._handle, int(L)))
+
+    def batches_in_flight(self) -> int:
+        """How many batches a labelling loop should keep in flight (one stream + workspace slot each).  Two everywhere but one
+        case: a BiLSTM behind a small Whisper encoder (tiny / base).  There the recurrence -- a few workgroups, serial in time --
+        is a large share of the forward and a third batch fills the CUs it leaves idle (default config.yaml head, 16 x 30 s:
+        56.5 / 75.0 / 82.4 / 80.4 k audio-s/s at 1 / 2 / 3 / 4 in flight; with Whisper-small, WavLM-large or no BiLSTM a third
+        batch costs 1-3 %: profiles/round2_inflight_sweep.json).  `WFL_INFLIGHT` overrides."""
+        env = os.environ.get("WFL_INFLIGHT")
+        if env:
+            return max(1, int(env))
+        small_whisper = self.encoder_type == "whisper" and self.arch.d_model <= 512
+        return 3 if (self.head_cfg["enable_bilstm"] and small_whisper) else 2
 
     def _workspace(self, B: int, L: int, device, slot: int = 0, need: int = 0):
         need = need or int(self._lib.wfl_workspace_bytes(self._handle, B, L))
