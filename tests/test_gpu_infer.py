@@ -120,6 +120,38 @@ def test_forced_alignment_and_cli(workdir):
     assert r.returncode == 1 and "neither --top-k nor --top-p" in r.stdout
 
 
+def test_three_batches_in_flight_label_like_one(workdir, monkeypatch):
+    """The pipelined loops with 3 workspace slots (the default for a BiLSTM behind a small Whisper encoder) against the same loops
+    with one batch at a time: 11 short files + a 65 s one, 2 rows per forward, so both the native-loader path and the chunked path
+    wrap around their slots several times.  Same segments, bit for bit."""
+    d, cfg, labels = workdir
+    cp, ck = str(d / "config.yaml"), str(d / "best_model.pt")
+    many = d / "many"
+    os.makedirs(many, exist_ok=True)
+    paths = []
+    for i in range(11):
+        p = str(many / f"{i:02d}.wav")
+        A.write_wav(p, synth.make_clip(900 + i, 16000 * (2 + i % 4), seed=31) * 0.8, 16000)
+        paths.append(p)
+    paths.append(str(d / "wavs" / "long.wav"))
+    monkeypatch.delenv("WFL_INFLIGHT", raising=False)
+    lab3 = I.Labeler(cp, ck, "cuda", batch_size=2)
+    assert lab3.n_inflight == 3
+    got3 = lab3.label_files(paths, lang_id=1, confidence_threshold=0.3, verbose=False)
+    chunks = [c for p in paths for c in A.load_items(p, 16000)]
+    slow3 = lab3._forward_items(chunks, 1, 0.3)
+    monkeypatch.setenv("WFL_INFLIGHT", "1")
+    lab1 = I.Labeler(cp, ck, "cuda", batch_size=2)
+    assert lab1.n_inflight == 1
+    got1 = lab1.label_files(paths, lang_id=1, confidence_threshold=0.3, verbose=False)
+    slow1 = lab1._forward_items(chunks, 1, 0.3)
+    assert got3 == got1 and all(len(g) > 0 for g in got3)
+    assert len(slow3) == len(chunks) == 14
+    for (i3, o3), (i1, o1) in zip(slow3, slow1):
+        assert np.array_equal(i3, i1) and np.array_equal(o3, o1)
+    assert got3[0] == _manual(lab1, paths[0], 1, 0.3)
+
+
 def test_bench_emits_one_json_line_with_the_contract_keys():
     """bench.py is what the driver times: a short run must print exactly one JSON line with the contract's keys (roofline and
     cpu_baseline objects included) and a status-clean forward."""

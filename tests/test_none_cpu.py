@@ -75,3 +75,16 @@ def test_oracle_mel_against_plain_numpy():
     assert np.abs(O.mel_filter_bank_htk(n_mels) - fb).max() <= 2e-5
     # every band sees at least one bin at 80 bands / 201 bins (no dead hidden channel)
     assert (fb.sum(0) > 0).all()
+
+
+def test_batches_in_flight_default_and_override(monkeypatch):
+    """tagger.batches_in_flight: 3 for a BiLSTM behind Whisper-tiny / -base, 2 everywhere else; WFL_INFLIGHT overrides."""
+    labels = synth.make_labels(3)
+    monkeypatch.delenv("WFL_INFLIGHT", raising=False)
+    assert BIOPhonemeTagger(synth.base_config("whisper"), labels).batches_in_flight() == 3            # default config.yaml head
+    assert BIOPhonemeTagger(synth.baseline_config(1), labels).batches_in_flight() == 2                # cfg2: no BiLSTM
+    assert BIOPhonemeTagger(synth.baseline_config(2), labels).batches_in_flight() == 2                # WavLM-large + BiLSTM
+    assert BIOPhonemeTagger(synth.baseline_config(3), labels).batches_in_flight() == 2                # Whisper-small + full head
+    assert BIOPhonemeTagger(_cfg(), labels).batches_in_flight() == 2                                  # mel front-end
+    monkeypatch.setenv("WFL_INFLIGHT", "4")
+    assert BIOPhonemeTagger(synth.baseline_config(1), labels).batches_in_flight() == 4
