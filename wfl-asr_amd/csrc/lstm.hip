@@ -71,7 +71,10 @@ typedef __attribute__((address_space(3))) void* lstm_lptr_t;
 #define LSTM_GX_AUX 0          // cache policy of the gx stream (2 = nt)
 #endif
 
-template <int H, int MAXT>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
+// RAG: clips of different lengths (LstmArgs::clip_T).  Its own instantiation, because a per-lane frame index turns the scalar row
+// arithmetic of the loader wave and of the output store into 64-bit vector arithmetic on the step's critical path: with clips of one
+// length (every Whisper batch) that cost 3.85 against 3.25 ms per 16-clip forward (A/B on one box, default head).
+template <int H, int MAXT, bool RAG>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   static_assert(MAXT % 2 == 0, "tiles are paired");
   constexpr int KS = H / 32;                     // K steps of 32 hidden units
@@ -178,11 +181,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   // against 0.7), +0.17 us per step at 16 clips and +0.43 at 64 (tools/micro/lstm_bench.hip, -DWFL_LSTM_NO_GX).  The loader wave has
   // its own vmcnt; it joins the compute waves' one barrier per step, in front of which it has seen step s + 1's data land.
   const float* gx_lane = p.gx + (p.lead + (long)clip_rd * p.P) * p.ldgx + dir * 4 * H + 4 * (slice * U + 2 * g);
-  const int Tc = p.clip_T ? p.clip_T[clip_rd] : p.T;     // frames of this lane's clip (LstmArgs::clip_T)
+  const int Tc = RAG ? p.clip_T[clip_rd] : p.T;          // frames of this lane's clip (LstmArgs::clip_T)
   if (wid == 4) {
     auto issue = [&](int s) __attribute__((always_inline)) {
       int t = dir == 0 ? s : Tc - 1 - s;             // (this lane's clip: its backward direction starts at its own last frame)
-      t = s < Tc ? t : 0;                            // steps beyond the clip's length: any valid row, the result is never stored
+      if (RAG) t = s < Tc ? t : 0;                   // steps beyond the clip's length: any valid row, the result is never stored
       const float* gp = gx_lane + (long)t * p.ldgx;
       char* dst = lstm_dyn + (long)(s & (LSTM_NR - 1)) * (4 * MAXT * 1024);
 #pragma unroll
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
           else __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, LSTM_SC1);          // write-through: any placement
         }
 #ifndef WFL_LSTM_NO_OUT       // (diagnostic builds: tools/micro/lstm_bench.hip)
-        if (clip < p.B && s < Tc) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
+        if (clip < p.B && (!RAG || s < Tc)) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
 #endif
       }
     }
@@ -349,11 +352,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   for (int s = 0; s < p.T; ++s) step(s);
 }
 
-template <int H, int MAXT>
-static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
+template <int H, int MAXT, bool RAG>
+static int launch_lstm_r(const LstmArgs& a, int groups, hipStream_t s) {
   const int teams = 2 * groups;
   constexpr int lds = LSTM_NR * 4 * MAXT * 1024;       // the gx ring (dynamic; the fragment images are static shared memory)
-  auto k = lstm_kernel<H, MAXT>;
+  auto k = lstm_kernel<H, MAXT, RAG>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
@@ -364,6 +367,11 @@ static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + 7) / 8)), dim3(LSTM_THREADS), lds, s, a);
 #endif
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int H, int MAXT>
+static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
+  return a.clip_T ? launch_lstm_r<H, MAXT, true>(a, groups, s) : launch_lstm_r<H, MAXT, false>(a, groups, s);
 }
 
 // Units per WG: 32 (four waves x one pair of 16-row tiles) when it divides H, else the largest multiple of 8 below that does.
