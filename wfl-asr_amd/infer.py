@@ -79,7 +79,7 @@ class Labeler:
             self.model.set_average_languages(list(self.lang2id.values()))
         if batch_size is None:
             # rows per forward.  A BiLSTM's recurrence costs the same ~1.2 us per time step for 16 clips as for 64 (clips run in
-            # groups of 16 on their own workgroups), so wide batches amortise it: default head, 64 rows 105 k audio-s/s, 16 rows 83 k
+            # groups of 16 on their own workgroups), so wide batches amortise it: default head, 64 rows 107 k audio-s/s, 16 rows 87 k
             # (DESIGN.md section 5).  A clip's tags do not depend on what shares its batch (bit-exact batch invariance).
             batch_size = int(os.environ.get("WFL_BATCH_SIZE", "64" if self.model.head_cfg["enable_bilstm"] else "16"))
         self.batch_size = int(batch_size)
