@@ -31,6 +31,9 @@ echo "== files -> .lab end to end"
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 2> /dev/null | tail -1 > $OUT/e2e_label_files.txt || exit 1
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --full-head --files 768 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
 echo "== lstm micro"
+if [ $ROOT/wfl-asr_amd/csrc/lstm.hip -nt $ROOT/tools/micro/lstm_bench_x ] || [ ! -x $ROOT/tools/micro/lstm_bench_x ]; then
+  echo "micro-benchmarks older than lstm.hip: rebuilding"; bash $ROOT/tools/micro/build.sh || exit 1
+fi
 (cd $ROOT/tools/micro && ./lstm_bench_stamps > $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 512 64 499 >> $OUT/lstm_step_breakdown.txt 2>&1; ./lstm_bench_x 384 64 1500 >> $OUT/lstm_step_breakdown.txt 2>&1)
 find $OUT -name "*.csv" | head -30
 echo done
