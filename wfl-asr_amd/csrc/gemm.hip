@@ -247,12 +247,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     int b = m / p.P, t = m - b * p.P;
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
-      ok[pass] = (m + pass * RPP < p.M) && t < (p.clip_T ? p.clip_T[b] : p.T);
+      ok[pass] = (m + pass * RPP < p.M) && t < p.T;
       tt[pass] = t;
       orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
       t += RPP;
-      while (t >= p.P) { t -= p.P; ++b; }    // (a pitch below RPP = 32 rows -- clips of at most 8 frames -- wraps more than once)
+      if (p.P >= RPP) { if (t >= p.P) { t -= p.P; ++b; } }
+      else while (t >= p.P) { t -= p.P; ++b; }    // (a pitch below RPP = 32 rows -- clips of at most 8 frames -- wraps more than once)
     }
+  }
+  if (p.clip_T) {                              // ragged batches: a clip's own frame count (behind a scalar branch: common.h, GemmArgs::clip_T)
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass)
+      if (ok[pass] && tt[pass] >= p.clip_T[(orow[pass] - p.c_lead) / p.c_pitch]) ok[pass] = false;
   }
   // Unconditional loads (a branch per load would make hipcc wait vmcnt(0) after each): rows that are not stored
   // are halo / tail rows of the residual's frame-row buffer, which exist; the positional row is clamped.

@@ -251,12 +251,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         int b = m / p.P, t = m - b * p.P;
 #pragma unroll
         for (int pass = 0; pass < NP; ++pass) {
-          ok[pass] = (m + pass * RPP < p.M) && t < (p.clip_T ? p.clip_T[b] : p.T) && (tid / CP + pass * RPP < HR);
+          ok[pass] = (m + pass * RPP < p.M) && t < p.T && (tid / CP + pass * RPP < HR);
           tt[pass] = t;
           orow[pass] = p.c_lead + (long)b * p.c_pitch + t;
           t += RPP;
-          while (t >= p.P) { t -= p.P; ++b; }
+          if (p.P >= RPP) { if (t >= p.P) { t -= p.P; ++b; } }
+          else while (t >= p.P) { t -= p.P; ++b; }    // (clips of at most 8 frames: a pitch below RPP wraps more than once)
         }
+      }
+      if (p.clip_T) {                          // ragged batches: a clip's own frame count (behind a scalar branch)
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass)
+          if (ok[pass] && tt[pass] >= p.clip_T[(orow[pass] - p.c_lead) / p.c_pitch]) ok[pass] = false;
       }
       // residual rows are prefetched four passes at a time (all accumulators of the other half are still live, so
       // registers are tight); the positional row (one launch per forward) is read in place

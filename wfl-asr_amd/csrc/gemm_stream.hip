@@ -287,7 +287,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       int t = m - b * p.P;
       if (t < 0) { t += p.P; --b; }
       if (t >= p.P) { t -= p.P; ++b; }
-      orow[u] = (m < p.M && t < (p.clip_T ? p.clip_T[b] : p.T)) ? (int)p.c_lead + b * p.c_pitch + t : -1;
+      orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * p.c_pitch + t : -1;
+    }
+    if (p.clip_T) {                                 // ragged batches: a clip's own frame count (a scalar branch around six loads: inside
+#pragma unroll                                      // the expression above they cost the LayerNorm-folded launches 2 us each)
+      for (int u = 0; u < MT; ++u)
+        if (orow[u] >= 0) {
+          const int b = (orow[u] - (int)p.c_lead) / p.c_pitch;
+          if (orow[u] - (int)p.c_lead - b * p.c_pitch >= p.clip_T[b]) orow[u] = -1;
+        }
     }
     // residual hi + lo halves: a ring of three 16-frame tiles in flight (all six at once would not fit the register file next
     // to the accumulators); tile u + 3 is requested as soon as tile u has been consumed
