@@ -145,7 +145,7 @@ class BIOPhonemeTagger:
         """How many batches a labelling loop should keep in flight (one stream + workspace slot each).  Two everywhere but one
         case: a BiLSTM behind a small Whisper encoder (tiny / base).  There the recurrence -- a few workgroups, serial in time --
         is a large share of the forward and a third batch fills the CUs it leaves idle (default config.yaml head, 16 x 30 s:
-        56.5 / 75.0 / 82.4 / 80.4 k audio-s/s at 1 / 2 / 3 / 4 in flight; with Whisper-small, WavLM-large or no BiLSTM a third
+        60.4 / 78.1 / 87.0 / 91.8 k audio-s/s at 1 / 2 / 3 / 4 in flight, not monotonic beyond; with Whisper-small, WavLM-large or no BiLSTM a third
         batch costs 1-3 %: profiles/round2_inflight_sweep.json).  `WFL_INFLIGHT` overrides."""
         env = os.environ.get("WFL_INFLIGHT")
         if env:
