@@ -101,9 +101,10 @@ class Labeler:
         def fill(k, host):
             chunk = items[k * Bs:(k + 1) * Bs]
             lens = np.zeros(Bs, dtype=np.int32)
-            for i, x in enumerate(chunk):
+            rows = host.numpy()                  # (a numpy row assignment is a plain memcpy, 0.2 ms per 30 s item; the same through
+            for i, x in enumerate(chunk):        #  torch's indexing was measured at 1-18 ms)
                 n = min(len(x), L)
-                host[i, :n] = torch.from_numpy(np.ascontiguousarray(x[:n]))
+                rows[i, :n] = x[:n]
                 lens[i] = n
             return lens, len(chunk)
 
@@ -241,8 +242,9 @@ class Labeler:
             if pin_out[slot] is None or pin_out[slot].numel() < need_out:
                 pin_out[slot] = torch.empty(need_out, dtype=torch.int32).pin_memory()
             host = pin_in[slot][:need_in].view(len(sel), n)
+            rows = host.numpy()
             for j, i in enumerate(sel):
-                host[j, :len(items[i])] = torch.from_numpy(np.ascontiguousarray(items[i]))
+                rows[j, :len(items[i])] = items[i]
             lens = None if same else np.array([len(items[i]) for i in sel], np.int32)
             with torch.cuda.stream(self._streams[slot]):
                 wav = host.to(self.device, non_blocking=True)
