@@ -263,16 +263,33 @@ void resample_f64(const std::vector<double>& x, int orig_freq, int new_freq, std
   const double base = (double)std::min(orig, nw) * rolloff;
   const int width = (int)std::ceil(lpw * orig / base);
   const int klen = 2 * width + orig;
-  std::vector<double> kern((size_t)nw * klen);
+  // Per output phase only the taps inside the window's support are kept (|t| < lowpass_filter_width: about 2 * width of the klen taps
+  // -- 35 of 475 for 44.1 -> 16 kHz).  The dense form multiplies the others by cos^2(pi / 2) = 3.7e-33, not 0: dropping them moves a
+  // sum by less than 1e-33 of its terms, far below a float64 ulp of any audible sample, and makes the loop 13 times shorter (216 ->
+  // 16 ms for a 30 s file at 44.1 kHz, which bounds the end-to-end rate of folders that are not 16 kHz).
   const double scale = base / orig;
-  for (int i = 0; i < nw; ++i)
+  std::vector<int> jlo(nw), cnt(nw);
+  int maxcnt = 0;
+  for (int i = 0; i < nw; ++i) {
+    int lo = klen, hi = -1;
     for (int j = 0; j < klen; ++j) {
+      const double t = (-(double)i / nw + (double)(j - width) / orig) * base;
+      if (t > -lpw && t < lpw) { if (j < lo) lo = j; hi = j; }
+    }
+    jlo[i] = hi >= lo ? lo : 0;
+    cnt[i] = hi >= lo ? hi - lo + 1 : 0;
+    maxcnt = std::max(maxcnt, cnt[i]);
+  }
+  std::vector<double> kern((size_t)nw * maxcnt, 0.0);
+  for (int i = 0; i < nw; ++i)
+    for (int q = 0; q < cnt[i]; ++q) {
+      const int j = jlo[i] + q;
       double t = (-(double)i / nw + (double)(j - width) / orig) * base;
       t = std::min(std::max(t, -lpw), lpw);
       const double c = std::cos(t * M_PI / lpw / 2.0);
       const double window = c * c;
       t *= M_PI;
-      kern[(size_t)i * klen + j] = (t == 0.0 ? 1.0 : std::sin(t) / t) * window * scale;
+      kern[(size_t)i * maxcnt + q] = (t == 0.0 ? 1.0 : std::sin(t) / t) * window * scale;
     }
   const size_t length = x.size();
   std::vector<double> xp(length + 2 * (size_t)width + orig, 0.0);
@@ -283,9 +300,11 @@ void resample_f64(const std::vector<double>& x, int orig_freq, int new_freq, std
   for (size_t f = 0; f < nfr; ++f) {
     const double* src = xp.data() + f * orig;
     for (int i = 0; i < nw; ++i) {
-      const double* k = kern.data() + (size_t)i * klen;
+      const double* k = kern.data() + (size_t)i * maxcnt;
+      const double* sj = src + jlo[i];
+      const int n = cnt[i];
       double acc = 0.0;
-      for (int j = 0; j < klen; ++j) acc += src[j] * k[j];
+      for (int q = 0; q < n; ++q) acc += sj[q] * k[q];
       out[f * nw + i] = acc;
     }
   }
