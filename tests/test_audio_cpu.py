@@ -123,3 +123,23 @@ def test_native_lab_text_equals_save_lab(tmp_path):
     pp.save_lab(p, segs)
     assert npost.format_lab_tuples(segs) == open(p, "rb").read()
     assert npost.format_lab_tuples([]) == b""
+
+
+def test_wav_sample_rate_reads_the_header_only(tmp_path):
+    p = str(tmp_path / "a.wav")
+    A.write_wav(p, np.zeros(100, np.float32), 44100)
+    assert A.wav_sample_rate(p) == 44100
+    A.write_wav(p, np.zeros(100, np.float32), 16000)
+    assert A.wav_sample_rate(p) == 16000
+    # a chunk in front of `fmt ` is skipped; no fmt chunk in the first 4 KiB, a truncated or foreign file, a missing file: None
+    raw = open(p, "rb").read()
+    with open(p, "wb") as f:
+        f.write(raw[:12] + b"LIST" + (6).to_bytes(4, "little") + b"abcdef" + raw[12:])
+    assert A.wav_sample_rate(p) == 16000
+    with open(p, "wb") as f:
+        f.write(raw[:20])
+    assert A.wav_sample_rate(p) is None
+    with open(p, "wb") as f:
+        f.write(b"not a wav file at all")
+    assert A.wav_sample_rate(p) is None
+    assert A.wav_sample_rate(str(tmp_path / "missing.wav")) is None

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--files", type=int, default=96)
     ap.add_argument("--full-head", action="store_true", help="the default config.yaml head (BiLSTM + Conformer + dilated) at the "
                     "Labeler's own batch size and batches in flight; prints the end-to-end rate only")
+    ap.add_argument("--rate", type=int, default=16000, help="sample rate of the files on disk (other than 16000: every file takes the "
+                    "general ingest path -- decode, resample, chunk -- and the end-to-end rate is printed alone)")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="wfl_e2e_")
     cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(1)
@@ -44,19 +46,21 @@ def main():
     os.makedirs(wavs)
     base = [synth.make_clip(5000 + i, 480000, seed=1) * 0.8 for i in range(8)]
     paths = []
+    if args.rate != 16000:
+        base = [A.resample(b.astype(np.float64), 16000, args.rate).astype(np.float32) for b in base]
     for i in range(args.files):
         p = os.path.join(wavs, f"{i:04d}.wav")
-        A.write_wav(p, base[i % 8], 16000)
+        A.write_wav(p, base[i % 8], args.rate)
         paths.append(p)
     lab = I.Labeler(cfg, sd, "cuda", batch_size=None if args.full_head else 16)
     lab.label_files(paths[:4 * lab.batch_size], lang_id=0, confidence_threshold=0.5, verbose=False)      # warm-up
     torch.cuda.synchronize()
-    if args.full_head:
+    if args.full_head or args.rate != 16000:
         t0 = time.perf_counter()
         out = lab.label_files(paths, lang_id=0, confidence_threshold=0.5, verbose=False)
         t_all = time.perf_counter() - t0
         n = len(paths)
-        print(f"default config.yaml head | files {n} x 30 s | rows per forward {lab.batch_size}, batches in flight {lab.n_inflight} | "
+        print(f"{'default config.yaml head' if args.full_head else 'cfg2 model'} | files {n} x 30 s at {args.rate} Hz | rows per forward {lab.batch_size}, batches in flight {lab.n_inflight} | "
               f"label_files end to end {1e3 * t_all / n:.2f} ms/file = {30 * n / t_all:.0f} audio-s/s; segments/file {np.mean([len(o) for o in out]):.0f}")
         return
 

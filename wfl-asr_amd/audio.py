@@ -22,6 +22,27 @@ import numpy as np
 from .postprocess import MAX_SEGMENT_DURATION, split_audio  # noqa: F401  (re-exported)
 
 
+def wav_sample_rate(path: str):
+    """Sample rate from the header alone (the first 4 KiB), or None when no `fmt ` chunk is found there / the file is not RIFF/WAVE."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(4096)
+    except OSError:
+        return None
+    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        return None
+    pos = 12
+    while pos + 8 <= len(head):
+        cid = head[pos:pos + 4]
+        size = struct.unpack("<I", head[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            if pos + 8 + 16 > len(head):
+                return None
+            return int(struct.unpack("<HHIIHH", head[pos + 8:pos + 24])[2])
+        pos += 8 + size + (size & 1)
+    return None
+
+
 def read_wav(path: str):
     """-> (float64 mono samples, sample_rate)."""
     with open(path, "rb") as f:

@@ -234,6 +234,19 @@ int decode_mono(const char* path, std::vector<double>& mono, int32_t* sr_out) {
     double v; memcpy(&v, p, 8); return v;
   };
   mono.resize(frames);
+  if (w.tag == 1 && w.bits == 16) {                             // the common case on its own loop (integers: no NaN to look for)
+    const unsigned char* p = w.pcm;
+    if (w.ch == 1) {
+      for (size_t i = 0; i < frames; ++i) { int16_t v; memcpy(&v, p + 2 * i, 2); mono[i] = (double)v / 32768.0; }
+    } else {
+      for (size_t i = 0; i < frames; ++i) {
+        int16_t v0, v1;
+        memcpy(&v0, p + 4 * i, 2); memcpy(&v1, p + 4 * i + 2, 2);
+        mono[i] = ((double)v0 / 32768.0 + (double)v1 / 32768.0) / 2.0;
+      }
+    }
+    return 0;
+  }
   for (size_t i = 0; i < frames; ++i) {
     // mono of 2 channels = (a + b) / 2, numpy's mean over a length-2 axis
     const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
@@ -292,14 +305,43 @@ void resample_f64(const std::vector<double>& x, int orig_freq, int new_freq, std
       kern[(size_t)i * maxcnt + q] = (t == 0.0 ? 1.0 : std::sin(t) / t) * window * scale;
     }
   const size_t length = x.size();
-  std::vector<double> xp(length + 2 * (size_t)width + orig, 0.0);
-  memcpy(xp.data() + width, x.data(), length * sizeof(double));
-  const size_t nfr = (xp.size() - klen) / orig + 1;
+  const size_t xlen = length + 2 * (size_t)width + orig;       // the zero-padded signal: `width` zeros in front, width + orig behind
+  const size_t nfr = (xlen - klen) / orig + 1;
+  // Frames whose taps all lie inside x read it in place; the few at either end go through a zero-extended copy of their window
+  // (a padded copy of the whole signal costs more than the sums: 10 MB of fresh pages per 30 s at 44.1 kHz).
+  const size_t span = (size_t)klen + (size_t)maxcnt;           // what the eight-at-a-time loop below may read from a frame's start
+  std::vector<double> edge(span);
   const size_t target = (size_t)std::ceil((double)nw * (double)length / orig);
   out.assign(nfr * nw, 0.0);
+  // Each output is one sequential sum (taps in ascending order, as the dense form adds them): a chain of dependent FMAs.  Eight
+  // phases run side by side, each over maxcnt taps -- the kernel rows are zero-padded, and x * 0.0 added to a sum leaves it as it is.
   for (size_t f = 0; f < nfr; ++f) {
-    const double* src = xp.data() + f * orig;
-    for (int i = 0; i < nw; ++i) {
+    const size_t p0 = f * (size_t)orig;                        // frame start in the padded signal = x index + width
+    const double* src;
+    if (p0 >= (size_t)width && p0 - width + span <= length) src = x.data() + (p0 - width);
+    else {
+      for (size_t j = 0; j < span; ++j) {
+        const size_t pj = p0 + j;
+        edge[j] = (pj >= (size_t)width && pj - width < length) ? x[pj - width] : 0.0;
+      }
+      src = edge.data();
+    }
+    int i = 0;
+    for (; i + 8 <= nw; i += 8) {
+      const double* k = kern.data() + (size_t)i * maxcnt;
+      const double* s[8];
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s[u] = src + jlo[i + u]; a[u] = 0.0; }
+      for (int q = 0; q < maxcnt; ++q) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += s[u][q] * k[(size_t)u * maxcnt + q];
+      }
+      double* o = &out[f * nw + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[u] = a[u];
+    }
+    for (; i < nw; ++i) {
       const double* k = kern.data() + (size_t)i * maxcnt;
       const double* sj = src + jlo[i];
       const int n = cnt[i];

@@ -354,7 +354,12 @@ class Labeler:
         lang_name = self._lang_name(lang_id)
         decided_fast = {}                                 # file index -> segments of its one <= 30 s item, natively loaded
         if self.model.encoder_type == "whisper" and len(audio_paths) > 0:
-            decided_fast = self._label_fast(audio_paths, lang_id, confidence_threshold, lang_name)
+            # only files whose header says 16 kHz are offered to the fast path (the others would be decoded there just to be turned
+            # away, and their rows forwarded empty); a header that cannot be read leaves the decision to the loader
+            cand = [fi for fi, p in enumerate(audio_paths) if A.wav_sample_rate(p) in (self.sr, None)]
+            if cand:
+                got = self._label_fast([audio_paths[fi] for fi in cand], lang_id, confidence_threshold, lang_name)
+                decided_fast = {cand[j]: seg for j, seg in got.items()}
         items, owner = [], []
         chunk_lens = []
 
