@@ -145,7 +145,9 @@ int32_t wfl_head(wfl_model* m, const float* hidden, int32_t B, int32_t T, const 
                  float* offsets, float* logits, int32_t* status, void* stream);
 
 /* Synchronise `stream` and report the device-side error word of the last forward run on this workspace (same bits as
- * `status`: every kernel of a forward ORs into one word that the forward clears when it starts).  Optional; 0 = ok. */
+ * `status`: every kernel of a forward ORs into one word that the forward clears when it starts).  Optional; 0 = ok.
+ * B, L: those of that forward (the word's place in the workspace follows the plan).  A workspace no forward has run on holds
+ * whatever its allocator left there: zero it once, or call this only after a forward. */
 int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_t B, int32_t L, void* stream);
 
 /* ---- single stages, exported for unit parity tests and profiling ---- */

@@ -371,24 +371,34 @@ class Labeler:
             return chunks
 
         slow = [fi for fi in range(len(audio_paths)) if fi not in decided_fast]
-        if len(slow) > 1:                                   # (the native loader releases the GIL: files decode / resample in parallel)
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(slow)))) as ex:
-                loaded = dict(zip(slow, ex.map(lambda fi: load_one(audio_paths[fi]), slow)))
-        else:
-            loaded = {fi: load_one(audio_paths[fi]) for fi in slow}
-        for fi, path in enumerate(audio_paths):
-            if fi in decided_fast:
-                continue
-            chunks = loaded[fi]
-            lens = [len(c) for c in chunks]
-            if verbose and len(chunks) > 1:
-                print(f"Audio is too long ({sum(lens)/self.sr:.1f}s), splitting...")
-            for c, n in zip(chunks, lens):
-                items.append(c)
-                owner.append(fi)
-                chunk_lens.append(n)
-        decided = self._forward_items(items, lang_id, confidence_threshold) if items else []
+        # The native loader releases the GIL: files decode / resample on worker threads, all submitted at once; the items are
+        # forwarded in waves, in file order, as their files arrive, so the forwards of one wave run under the loading of the next.
+        decided = []
+        pool = None
+        try:
+            if len(slow) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                pool = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(slow))))
+                futs = [pool.submit(load_one, audio_paths[fi]) for fi in slow]
+            wave = max(8 * self.batch_size, 64)                 # items per wave: enough batches to fill the pipeline's slots
+            start = 0
+            for j, fi in enumerate(slow):
+                chunks = futs[j].result() if pool is not None else load_one(audio_paths[fi])
+                lens = [len(c) for c in chunks]
+                if verbose and len(chunks) > 1:
+                    print(f"Audio is too long ({sum(lens)/self.sr:.1f}s), splitting...")
+                for c, n in zip(chunks, lens):
+                    items.append(c)
+                    owner.append(fi)
+                    chunk_lens.append(n)
+                if len(items) - start >= wave and j + 1 < len(slow):
+                    decided.extend(self._forward_items(items[start:], lang_id, confidence_threshold))
+                    start = len(items)
+            if len(items) > start:
+                decided.extend(self._forward_items(items[start:], lang_id, confidence_threshold))
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True, cancel_futures=True)
         results = [[] for _ in audio_paths]
         clock = [0.0] * len(audio_paths)
         for (ids, offs), fi, n in zip(decided, owner, chunk_lens):

@@ -164,14 +164,16 @@ class BIOPhonemeTagger:
             if ws is None or ws.numel() < need or ws.device != device:
                 if any(k[-1] == slot for k in self._graphs):
                     raise _lib.WflError("workspace must not grow while captured graphs hold its address")
-                self._ws_extra[slot] = ws = torch.empty(need, dtype=torch.uint8, device=device)
+                self._ws_extra[slot] = ws = torch.zeros(need, dtype=torch.uint8, device=device)   # (zeros: see below)
             return ws
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             if any(k[-1] == 0 for k in self._graphs):
                 raise _lib.WflError("workspace must not grow while captured graphs hold its address; "
                                     "label the largest batch first or create a new tagger")
             self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+            # zeros, not empty: the forward's error word lives in the workspace, and `check()` on a slot no forward has run on yet
+            # must read 0 rather than whatever the allocator hands back (a one-time fill of about 1 GB per slot)
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=device)
         return self._ws
 
     def _check_lang(self, lang_id, B):
