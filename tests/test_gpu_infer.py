@@ -134,8 +134,14 @@ def test_three_batches_in_flight_label_like_one(workdir, monkeypatch):
         A.write_wav(p, synth.make_clip(900 + i, 16000 * (2 + i % 4), seed=31) * 0.8, 16000)
         paths.append(p)
     paths.append(str(d / "wavs" / "long.wav"))
+    for i in range(7):                                   # files at other rates take the general path: with long.wav 10 items in 3 waves
+        p = str(many / f"r{i}.wav")
+        rate = (44100, 22050, 8000)[i % 3]
+        A.write_wav(p, A.resample(synth.make_clip(930 + i, 16000 * (1 + i % 3), seed=31).astype(np.float64), 16000, rate) * 0.7, rate)
+        paths.append(p)
     monkeypatch.delenv("WFL_INFLIGHT", raising=False)
     lab3 = I.Labeler(cp, ck, "cuda", batch_size=2)
+    lab3._wave_items = 4
     assert lab3.n_inflight == 3
     got3 = lab3.label_files(paths, lang_id=1, confidence_threshold=0.3, verbose=False)
     chunks = [c for p in paths for c in A.load_items(p, 16000)]
@@ -146,10 +152,11 @@ def test_three_batches_in_flight_label_like_one(workdir, monkeypatch):
     got1 = lab1.label_files(paths, lang_id=1, confidence_threshold=0.3, verbose=False)
     slow1 = lab1._forward_items(chunks, 1, 0.3)
     assert got3 == got1 and all(len(g) > 0 for g in got3)
-    assert len(slow3) == len(chunks) == 14
+    assert len(slow3) == len(chunks) == 21
     for (i3, o3), (i1, o1) in zip(slow3, slow1):
         assert np.array_equal(i3, i1) and np.array_equal(o3, o1)
     assert got3[0] == _manual(lab1, paths[0], 1, 0.3)
+    assert got3[-1] == _manual(lab1, paths[-1], 1, 0.3) and got3[11] == _manual(lab1, paths[11], 1, 0.3)   # a resampled file, the long one
 
 
 def test_bench_emits_one_json_line_with_the_contract_keys():

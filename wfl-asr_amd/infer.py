@@ -380,7 +380,8 @@ class Labeler:
                 from concurrent.futures import ThreadPoolExecutor
                 pool = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(slow))))
                 futs = [pool.submit(load_one, audio_paths[fi]) for fi in slow]
-            wave = max(8 * self.batch_size, 64)                 # items per wave: enough batches to fill the pipeline's slots
+            wave = getattr(self, "_wave_items", None) or max(8 * self.batch_size, 64)   # items per wave: enough batches to fill
+                                                                                        # the pipeline's slots (tests set a small one)
             start = 0
             for j, fi in enumerate(slow):
                 chunks = futs[j].result() if pool is not None else load_one(audio_paths[fi])
