@@ -183,7 +183,7 @@ def load_items(path: str, sample_rate: int = 16000):
     from . import _lib
     lib = _lib.load()
     chunk = int(MAX_SEGMENT_DURATION * sample_rate)
-    rows = 4
+    rows = 4                       # (pages of rows that stay unused are never touched; the library reports how many it needs beyond)
     while True:
         buf = np.empty((rows, chunk), np.float32)
         n_rows, sr = C.c_int32(0), C.c_int32(0)
@@ -195,7 +195,7 @@ def load_items(path: str, sample_rate: int = 16000):
             continue
         if st != 0:
             return None
-        return [buf[r, :lens[r]].copy() for r in range(n_rows.value)]
+        return [buf[r, :lens[r]] for r in range(n_rows.value)]       # views: `buf` belongs to this call alone
 
 
 def chunk_clip(audio: np.ndarray, sr: int = 16000):
