@@ -65,3 +65,25 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_no_object_holds_the_packed_f32_form_that_fails_beside_mfma_waves(libpath, tmp_path):
+    """gfx950: v_pk_{fma,mul,add}_f32 with op_sel[1] = 1 (the low lane takes src1's high half) returns a wrong low half in lanes 48-63
+    now and then while another wave of the SIMD issues MFMAs (round 3: tools/micro/conv0_probe.hip; the cause of round 2's conv0
+    corruption).  build.py checks the device assembly of every object; here: every object of the library passes, and the checker does
+    catch the form."""
+    from wfl_asr_amd import build as B
+    objs = [os.path.join(B.OBJ, os.path.basename(s)[:-4] + ".o") for s in B.sources()]
+    assert len(objs) >= 10
+    for o in objs:
+        B.check_device_asm(o)
+    bad = tmp_path / f"x-hip-amdgcn-amd-amdhsa-{B.ARCH}.s"
+    bad.write_text("\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0,1]\n"
+                   "\tv_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]\n"
+                   "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,0,0]\n")
+    B.check_device_asm(str(tmp_path / "x.o"))                      # the safe selections pass
+    for line in ("\tv_pk_fma_f32 v[34:35], v[34:35], v[50:51], 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n",
+                 "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]\n", "\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,1] op_sel_hi:[0,1]\n"):
+        bad.write_text(line)
+        with pytest.raises(RuntimeError, match="op_sel"):
+            B.check_device_asm(str(tmp_path / "x.o"))

@@ -115,6 +115,28 @@ def test_native_items_equal_python_path(tmp_path):
     assert A.load_items(str(tmp_path / "missing.wav")) is None
 
 
+def test_native_decoder_leaves_non_finite_samples_to_the_python_path(tmp_path):
+    """A float WAV holding +-Inf or NaN: the native resampler's zero-padded taps would spread Inf * 0.0 = NaN into outputs the sample
+    must not reach, so the native decoder refuses the file (status 1 -> None) and the caller falls back to audio.py, which follows
+    numpy exactly; a merely large finite sample is still taken and equals the Python path."""
+    rng = np.random.RandomState(9)
+    x = (rng.randn(44100) * 0.1).astype(np.float32)
+    for bad in (np.inf, -np.inf, np.nan):
+        y = x.copy()
+        y[20000] = bad
+        p = str(tmp_path / "bad.wav")
+        _raw_wav(p, 3, 1, 44100, 32, y.tobytes())
+        assert A.load_items(p, 16000) is None
+        _raw_wav(p, 3, 1, 16000, 32, y.tobytes())
+        assert A.load_items(p, 16000) is None
+    y = x.copy()
+    y[20000] = 3.0e30
+    p = str(tmp_path / "big.wav")
+    _raw_wav(p, 3, 1, 44100, 32, y.tobytes())
+    got, ref = A.load_items(p, 16000), A.chunk_clip(A.load_clip(p, 16000), 16000)
+    assert got is not None and len(got) == len(ref) == 1 and np.abs(got[0] - ref[0]).max() <= 2e-7
+
+
 def test_native_lab_text_equals_save_lab(tmp_path):
     from wfl_asr_amd import native_post as npost
     from wfl_asr_amd import postprocess as pp

@@ -7,3 +7,11 @@ F="-O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-result 
 /opt/rocm/bin/hipcc $F -DWFL_LSTM_STAMPS tools/micro/lstm_bench.hip -o tools/micro/lstm_bench_stamps
 /opt/rocm/bin/hipcc $F tools/micro/lstm_bench.hip -o tools/micro/lstm_bench_x
 echo built tools/micro/lstm_bench_stamps tools/micro/lstm_bench_x
+# the conv0 / packed-f32 probes: conv0 compiled as round 2 did (SLP vectoriser on), as the library does now, and
+# with a neighbour attention kernel that holds no MFMA instruction
+P="-O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-result -I wfl-asr_amd/csrc -I include"
+/opt/rocm/bin/hipcc $P tools/micro/conv0_probe.hip -o tools/micro/conv0_probe
+/opt/rocm/bin/hipcc $P -fno-slp-vectorize tools/micro/conv0_probe.hip -o tools/micro/conv0_probe_noslp
+/opt/rocm/bin/hipcc $P -DWFL_ABL_ATTN=2 tools/micro/conv0_probe.hip -o tools/micro/conv0_probe_nomfma
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result tools/micro/trans_war_probe.hip -o tools/micro/trans_war_probe
+echo built tools/micro/conv0_probe tools/micro/conv0_probe_noslp tools/micro/conv0_probe_nomfma tools/micro/trans_war_probe

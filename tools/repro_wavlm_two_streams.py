@@ -2,8 +2,9 @@
 """Diagnostic (not product): a WavLM-base encoder forward on one HIP stream beside other WavLM-base forwards on a second stream
 (another model instance, separate workspaces), compared bit for bit with its single-stream result; and the same two forwards
 alternating on ONE stream.  Round 2 found 15-40 % of the two-stream runs different: conv0's group-norm kernel produced wrong rows
-when its workgroups shared a CU with another forward's prefetching-attention workgroups (mechanism not understood; DESIGN.md
-section 7).  With conv0 given its CUs to itself (wavlm.hip; WFL_CONV0_LDS_PAD=0 undoes it) both lines read 0 of 96.
+when its workgroups shared a CU with another forward's attention workgroups.  Round 3 found the cause with tools/micro/conv0_probe.hip
+(a packed-f32 instruction form that is unsafe beside another wave's MFMAs: DESIGN.md section 7); with conv0 compiled without it both
+lines read 0 of 96.
 usage: repro_wavlm_two_streams.py"""
 import os, sys, dataclasses
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libwfl_asr_hip.so")
+# WFL_LIB_PATH: an alternative build of the same library (A/B runs of compiler flags: tools/build_variant.sh); never a fallback
+LIB_PATH = os.environ.get("WFL_LIB_PATH") or os.path.join(PKG, "libwfl_asr_hip.so")
 ABI_VERSION = 2
 
 

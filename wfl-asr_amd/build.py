@@ -16,6 +16,28 @@ ARCH = "gfx950"
 # form hipcc (ROCm 7.2) rotates the 64 accumulator registers of the software-pipelined GEMM loop through
 # v_accvgpr_mov every iteration (~40 extra instructions per K tile).
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# -save-temps=obj leaves the device assembly next to each object; check_device_asm() reads it (below).
+FLAGS += ["-save-temps=obj"]
+# wavlm.hip: no SLP vectoriser, i.e. no compiler-made packed-f32 instructions in conv0 (the note at conv0_group_kernel)
+PER_FILE_FLAGS = {"wavlm.hip": ["-fno-slp-vectorize"]}
+
+# Packed-f32 VALU instructions whose LOW lane takes the HIGH half of src1 (op_sel[1] = 1) return a wrong low half in lanes 48-63, now and
+# then, while another wave of the SIMD issues MFMAs (gfx950, found in round 3: tools/micro/conv0_probe.hip).  No
+# object of this library may contain one: the build fails instead of shipping a kernel that is wrong only beside a neighbour.
+import re
+_BAD_PK = re.compile(r"^\s*v_pk_(fma|mul|add|max|min)_f32\b.*\bop_sel:\[[01],1")
+
+
+def check_device_asm(obj: str) -> None:
+    base = obj[:-2]
+    asm = f"{base}-hip-amdgcn-amd-amdhsa-{ARCH}.s"
+    if not os.path.exists(asm):
+        raise RuntimeError(f"{asm} is missing: cannot check the device code of {obj} (was it built without -save-temps=obj?)")
+    with open(asm, "r", errors="replace") as f:
+        for ln, line in enumerate(f, 1):
+            if _BAD_PK.match(line):
+                raise RuntimeError(f"{asm}:{ln}: {line.strip()}\n  a packed-f32 instruction with op_sel[1] = 1 (src1's high half feeding the low "
+                                   "lane) is not safe beside MFMA waves on gfx950; compile the file with -fno-slp-vectorize or restructure the code")
 
 
 def _hipcc() -> str:
@@ -33,7 +55,7 @@ def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in deps + [os.path.abspath(__file__)])
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -47,7 +69,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc, *FLAGS, "-I", INCLUDE, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []), "-I", INCLUDE, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -59,6 +81,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
+    for obj in objs:
+        check_device_asm(obj)
+        for f in os.listdir(OBJ):        # keep the object and the device assembly; drop -save-temps' other by-products (they would travel)
+            if f.startswith(os.path.basename(obj)[:-2] + "-") or f.startswith(os.path.basename(obj)[:-2] + ".hip-"):
+                if not f.endswith(f"-{ARCH}.s"):
+                    os.remove(os.path.join(OBJ, f))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
     return LIB

@@ -23,6 +23,16 @@ static __device__ __forceinline__ bf16x4 ds_read_tr(const char* p) {
   return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)p));
 }
 
+#if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 2      // (diagnostic build of tools/micro/conv0_probe.hip: no matrix instructions; results are wrong)
+static __device__ __forceinline__ f32x4 attn_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c[e] = fmaf(bf2f(a[e]), bf2f(b[e + 4]), c[e]);
+  return c;
+}
+#else
+#define attn_mfma(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+
 template <int HD>
 static __device__ __forceinline__ int k_swz(int row) {
   constexpr int CPR = HD / 8;                 // 16-byte chunks per K row
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const bf16x8 kf = *(const bf16x8*)(Ks + r * (HD * 2) + (((ks * 4 + g) ^ k_swz<HD>(r)) << 4));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          st[qt][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][kk], 0, 0, 0);
+          st[qt][kk] = attn_mfma(kf, qf[qt][ks], st[qt][kk]);
       }
     }
     if (BIAS) {
@@ -255,11 +265,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         bf16x8 t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+#if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 1     // (diagnostic build of tools/micro/conv0_probe.hip: no transcendental instructions)
+          t[e] = f2bf(st[qt][2 * s2][e] * 0.001f);
+          t[4 + e] = f2bf(st[qt][2 * s2 + 1][e] * 0.001f);
+#else
           t[e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2][e]));
           t[4 + e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2 + 1][e]));
+#endif
         }
         pf[qt][s2] = t;
-        osum[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, t, osum[qt], 0, 0, 0);
+        osum[qt] = attn_mfma(ones, t, osum[qt]);
       }
     }
 
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][s2], o[qt][dt], 0, 0, 0);
+          o[qt][dt] = attn_mfma(vf, pf[qt][s2], o[qt][dt]);
       }
     }
     if (PREFETCH && kt + 1 < ntiles) {

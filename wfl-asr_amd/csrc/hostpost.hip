@@ -201,7 +201,7 @@ bool parse_wav(const std::vector<unsigned char>& d, WavInfo& w) {
 }
 
 // Decode a WAV file to float64 mono samples (soundfile.read semantics, 2 channels averaged).
-// status: 0 ok; 1 not a WAV / unsupported encoding / NaN samples; 2 more than 2 channels; 4 cannot open
+// status: 0 ok; 1 not a WAV / unsupported encoding / non-finite samples; 2 more than 2 channels; 4 cannot open
 int decode_mono(const char* path, std::vector<double>& mono, int32_t* sr_out) {
   *sr_out = 0;
   FILE* f = fopen(path, "rb");
@@ -250,7 +250,9 @@ int decode_mono(const char* path, std::vector<double>& mono, int32_t* sr_out) {
   for (size_t i = 0; i < frames; ++i) {
     // mono of 2 channels = (a + b) / 2, numpy's mean over a length-2 axis
     const double x = w.ch == 1 ? sample(i) : (sample(2 * i) + sample(2 * i + 1)) / 2.0;
-    if (x != x) return 1;                                      // numpy's max would propagate the NaN: leave it to the Python path
+    if (!std::isfinite(x)) return 1;                           // NaN: numpy's max would propagate it; +-Inf: the resampler's zero-padded taps
+                                                               // would turn it into NaN (Inf * 0.0) in outputs it must not reach -- both go
+                                                               // to the Python path (audio.py), which follows numpy / the reference exactly
     mono[i] = x;
   }
   return 0;

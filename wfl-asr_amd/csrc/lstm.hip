@@ -41,6 +41,7 @@
 //   launch finishes without further waiting.  Launches are cut so that one launch never needs more than 128 resident
 //   workgroups: two such launches (two batches in flight on two streams) always fit the 256 CUs together.
 #include "common.h"
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -406,7 +407,35 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
   a.ngroups = groups;
   // tags of an earlier launch must not validate: clear the granule images and the roll call (a kernel, not a memset node: common.h)
   if (wfl_launch_fill_i32((int*)exchange, 2L * groups * 2 * 16 * (a.H / 2) * 2 + 2L * groups * 64 * 2, 0, s)) return -3;
-  // at most 128 resident workgroups per launch, so that two launches in flight (two streams) always fit the chip together
+  // Residency contract.  A team (the G workgroups of one direction of one group of 16 clips) makes progress only while ALL its
+  // workgroups are resident -- one per CU, ~133 KiB of LDS each -- and launches are plain, so nothing checks that.  Two rules keep a
+  // team from ever waiting on a CU that another waiting team holds:
+  //   (1) a launch has at most 128 workgroups (whole teams), half the chip;
+  //   (2) recurrence launches of one device run ONE AT A TIME, whatever the number of batches in flight: each launch waits for the
+  //       event recorded behind the previous one (any stream, any model) before it starts.  What other streams run meanwhile are
+  //       GEMM / attention / element-wise kernels, which finish without waiting for anybody: the recurrence's workgroups take their CUs
+  //       as those kernels' workgroups retire (at worst one persistent GEMM launch later).
+  // Round 2 relied on (1) alone ("two launches always fit the chip"), which three or more batches in flight -- the default for this
+  // head -- broke: partially resident teams of several launches held each other's CUs until other streams' kernels drained
+  // (the cfg3 sweep that fell from 15.2 k to 5.0 k audio-s/s at four in flight).  Overlap is not lost: a batch's
+  // recurrence still runs under the other batches' GEMMs, only never under another recurrence.
+  // (Not while the stream is being captured into a graph: an event of another stream would pull that stream into the capture.  Graph
+  //  replay keeps at most two slots in flight, for which (1) is enough.)
+  static std::mutex chain_mu;
+  static hipEvent_t chain_ev[32] = {nullptr};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 31;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  const bool chained = cap == hipStreamCaptureStatusNone;
+  std::unique_lock<std::mutex> chain_lock(chain_mu, std::defer_lock);
+  if (chained) {
+    chain_lock.lock();                     // (wait -> launches -> record must not interleave with another host thread's)
+    if (!chain_ev[dev]) {
+      if (hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) return -2;
+    } else if (hipStreamWaitEvent(s, chain_ev[dev], 0) != hipSuccess) return -3;
+  }
   const int per = 128 / (2 * a.G) > 0 ? 128 / (2 * a.G) : 1;
   for (int g0 = 0; g0 < groups; g0 += per) {
     a.grp0 = g0;
@@ -426,5 +455,6 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
     }
     if (r) return r;
   }
+  if (chained && hipEventRecord(chain_ev[dev], s) != hipSuccess) return -3;
   return 0;
 }

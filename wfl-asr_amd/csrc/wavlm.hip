@@ -63,9 +63,22 @@ static __device__ __forceinline__ void wav_norm(const Conv0Args& p, int b, float
 }
 
 #define C0_TT 512          // time steps per workgroup
+// Frames leave LDS four at a time: frames 4m .. 4m+3 start at sample 20 m = byte 80 m, so seven 16-byte-aligned ds_read_b128 cover the
+// 25 samples they need (round 2 read every frame's ten samples on their own).
+//
+// THIS TRANSLATION UNIT IS COMPILED WITH -fno-slp-vectorize (build.py).  Round 2 saw conv0's second pass produce wrong rows now and then
+// while another forward's attention workgroups shared its CUs, and padded the kernel's LDS request so that it had its CUs to itself.
+// Round 3 found the cause (tools/micro/conv0_probe.hip, profiles/round3_conv0_probe.txt): hipcc's SLP vectoriser
+// had packed the two channels of a thread into v_pk_fma_f32 and, for the broadcast sample operand, emitted the form with
+// op_sel:[0,1,0] -- the LOW lane takes the HIGH half of src1.  On gfx950 a packed-f32 instruction of that form (v_pk_fma / v_pk_mul /
+// v_pk_add with op_sel[1] = 1) returns a low-half result computed as if that operand were zero, in lanes 48-63, about 3.5e-4 of the
+// time, WHILE ANOTHER WAVE ON THE SAME SIMD ISSUES MFMA INSTRUCTIONS; never without such a neighbour, and never for the other operand
+// selections (src0, src2, op_sel_hi, v_pk_mov_b32) -- each checked with pinned instruction sequences.  conv0 was the only kernel of the
+// library that contained the form, and the only one ever seen wrong.  Without the SLP vectoriser no packed f32 instruction is left in
+// this file; build.py additionally refuses any object of the library whose device code contains the form.
 template <bool APPLY>
 __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
-  __shared__ float xs[C0_TT * 5 + 16];
+  __shared__ __attribute__((aligned(16))) float xs[C0_TT * 5 + 16];
   const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
   const int Lb = p.lens ? p.lens[b] : p.L;                      // this clip's samples and level-0 frames
   const int T0b = p.lens ? (Lb >= 10 ? (Lb - 10) / 5 + 1 : 0) : p.T0;
@@ -73,44 +86,54 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
   float mean, rstd;
   wav_norm(p, b, mean, rstd);
   const float* w = p.wav + (long)b * p.ldw;
-  for (int i = threadIdx.x; i < nt * 5 + 5; i += 256) {
+  // (the whole array is filled: a group of four frames reads up to three frames past nt, whose results are dropped)
+  for (int i = threadIdx.x; i < C0_TT * 5 + 16; i += 256) {
     const long s = (long)t0 * 5 + i;
-    xs[i] = s < Lb ? (w[s] - mean) * rstd : 0.f;
+    xs[i] = (i < nt * 5 + 5 && s < Lb) ? (w[s] - mean) * rstd : 0.f;
   }
   __syncthreads();
   for (int c0 = threadIdx.x * 2; c0 < p.C; c0 += 512) {
     float wa[10], wb[10];
 #pragma unroll
     for (int j = 0; j < 10; ++j) { wa[j] = p.w[c0 * 10 + j]; wb[j] = p.w[(c0 + 1) * 10 + j]; }
-    if (!APPLY) {
-      float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
-      for (int t = 0; t < nt; ++t) {
-        float ya = 0.f, yb = 0.f;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) { const float x = xs[t * 5 + j]; ya = fmaf(wa[j], x, ya); yb = fmaf(wb[j], x, yb); }
-        sa += ya; qa += ya * ya; sb += yb; qb += yb * yb;
-      }
-      // partial sums of this time block; conv0_stats_reduce_kernel adds the blocks up in a fixed order (deterministic)
-      float* st = p.cpart + (((long)b * gridDim.x + blockIdx.x) * p.C + c0) * 2;
-      *(f32x4*)st = (f32x4){sa, qa, sb, qb};
-    } else {
+    float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;               // !APPLY: this time block's partial sums
+    float sca = 0.f, scb = 0.f, sha = 0.f, shb = 0.f;           // APPLY: the channel's GroupNorm as y * sc + sh
+    bf16_t* op = nullptr;
+    if (APPLY) {
       const double* st = p.cstats + ((long)b * p.C + c0) * 2;
       const double ma = st[0] / T0b, mb = st[2] / T0b;
       const double va = st[1] / T0b - ma * ma, vb = st[3] / T0b - mb * mb;
-      const float sca = (float)(1.0 / sqrt((va > 0 ? va : 0) + 1e-5)) * p.gamma[c0];
-      const float scb = (float)(1.0 / sqrt((vb > 0 ? vb : 0) + 1e-5)) * p.gamma[c0 + 1];
-      const float sha = p.beta[c0] - (float)ma * sca, shb = p.beta[c0 + 1] - (float)mb * scb;
-      bf16_t* op = p.out + (p.lead + (long)b * p.P + t0) * p.C + c0;
-      for (int t = 0; t < nt; ++t) {
-        float ya = 0.f, yb = 0.f;
+      sca = (float)(1.0 / sqrt((va > 0 ? va : 0) + 1e-5)) * p.gamma[c0];
+      scb = (float)(1.0 / sqrt((vb > 0 ? vb : 0) + 1e-5)) * p.gamma[c0 + 1];
+      sha = p.beta[c0] - (float)ma * sca; shb = p.beta[c0 + 1] - (float)mb * scb;
+      op = p.out + (p.lead + (long)b * p.P + t0) * p.C + c0;
+    }
+    for (int m = 0; m * 4 < nt; ++m) {
+      float x[28];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) { const float x = xs[t * 5 + j]; ya = fmaf(wa[j], x, ya); yb = fmaf(wb[j], x, yb); }
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-        bf16x2 o;
-        o[0] = f2bf(gelu_erf(fmaf(ya, sca, sha)));
-        o[1] = f2bf(gelu_erf(fmaf(yb, scb, shb)));
-        *(bf16x2*)(op + (long)t * p.C) = o;
+      for (int q = 0; q < 7; ++q) *(f32x4*)(x + 4 * q) = *(const f32x4*)(xs + 20 * m + 4 * q);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int t = m * 4 + f;
+        if (t >= nt) break;
+        float ya = 0.f, yb = 0.f;                                // (same FMA order as ever: tap 0 first)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { ya = fmaf(wa[j], x[5 * f + j], ya); yb = fmaf(wb[j], x[5 * f + j], yb); }
+        if (!APPLY) {
+          sa += ya; qa += ya * ya; sb += yb; qb += yb * yb;
+        } else {
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+          bf16x2 o;
+          o[0] = f2bf(gelu_erf(fmaf(ya, sca, sha)));
+          o[1] = f2bf(gelu_erf(fmaf(yb, scb, shb)));
+          *(bf16x2*)(op + (long)t * p.C) = o;
+        }
       }
+    }
+    if (!APPLY) {
+      // partial sums of this time block; conv0_stats_reduce_kernel adds the blocks up in a fixed order (deterministic)
+      float* st = p.cpart + (((long)b * gridDim.x + blockIdx.x) * p.C + c0) * 2;
+      *(f32x4*)st = (f32x4){sa, qa, sb, qb};
     }
   }
 }
@@ -193,23 +216,10 @@ int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s) {
   if (group_norm) {
     if (!a.cpart) return -1;
     dim3 grid((a.T0 + C0_TT - 1) / C0_TT, a.B);
-    // The two conv0 passes ask for 136 KiB of dynamic LDS they never touch, so that no other workgroup shares their CU.  Found in
-    // round 2: a conv0_group workgroup that shares a CU with workgroups of the prefetching attention kernels (another forward on
-    // another stream) now and then produces wrong rows -- 14-18 of 96 WavLM-base forwards differed, none with a CU of its own
-    // (the mechanism is not understood: neither kernel leaves its LDS allocation).  WFL_CONV0_LDS_PAD=0 removes
-    // the padding.
-    static int pad = -1;
-    static WflOncePerDevice attr_once;
-    if (pad < 0) { const char* e = getenv("WFL_CONV0_LDS_PAD"); pad = e ? atoi(e) : 136 * 1024; }
-    if (pad > 0 && attr_once.need()) {
-      if (hipFuncSetAttribute((const void*)conv0_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad) != hipSuccess ||
-          hipFuncSetAttribute((const void*)conv0_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad) != hipSuccess)
-        return -2;
-    }
-    const int dbg_lds = pad;
-    hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), dbg_lds, s, a);
+    // (no LDS padding any more: see the note at conv0_group_kernel)
+    hipLaunchKernelGGL(conv0_group_kernel<false>, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(conv0_stats_reduce_kernel, dim3((a.C + 255) / 256, a.B), dim3(256), 0, s, a.cpart, (int)grid.x, a.C, a.cstats);
-    hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), dbg_lds, s, a);
+    hipLaunchKernelGGL(conv0_group_kernel<true>, grid, dim3(256), 0, s, a);
   } else {
     int bx = (a.T0 + 3) / 4;
     if (bx > 2048) bx = 2048;
