@@ -76,6 +76,7 @@ __global__ __launch_bounds__(512) void dma_kernel(const char* A, long lda, const
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+static int g_grid = 256;      // workgroups per launch (512: two per CU when their LDS and registers allow it)
 template <int RB, int MM>
 static void run(const char* name, const char* A, long lda, const char* W, long ldw, int rowsA, int rowsW, int ksteps, int kb, int share, int nst,
                 float* sink, unsigned long long* cyc) {
@@ -85,22 +86,22 @@ static void run(const char* name, const char* A, long lda, const char* W, long l
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, A, lda, W, ldw, rowsA, rowsW, ksteps, kb, share, nst, sink, cyc);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(g_grid), dim3(512), lds, 0, A, lda, W, ldw, rowsA, rowsW, ksteps, kb, share, nst, sink, cyc);
   hipDeviceSynchronize();
   hipEventRecord(e0);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, A, lda, W, ldw, rowsA, rowsW, ksteps, kb, share, nst, sink, cyc);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(g_grid), dim3(512), lds, 0, A, lda, W, ldw, rowsA, rowsW, ksteps, kb, share, nst, sink, cyc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  std::vector<unsigned long long> h(256);
-  hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> h(g_grid);
+  hipMemcpy(h.data(), cyc, g_grid * 8, hipMemcpyDeviceToHost);
   double avg = 0;
   for (auto v : h) avg += v;
-  avg /= 256;
+  avg /= g_grid;
   const double us = ms * 1e3 / reps;
-  const double bytes = (double)(rowsA + rowsW) * kb * ksteps;
+  const double bytes = (double)(rowsA + rowsW) * kb * ksteps * (g_grid / 256.0);     // per CU
   printf("%-34s share=%3d nst=%d RB=%3d mfma/step=%2d  %8.1f us  %6.1f GB/s/CU  %6.2f TB/s chip  %5.1f B/clk/CU  (%.0f cyc/step, clk %.2f GHz)\n", name, share, nst, RB, MM, us,
          bytes / us / 1e3, bytes * 256 / us / 1e6, bytes / avg, avg / ksteps, avg / us / 1e3);
 }
@@ -111,7 +112,7 @@ int main() {
   char *A, *W; float* sink; unsigned long long* cyc;
   hipMalloc(&A, 256L * rowsA * lda + (1 << 20));
   hipMalloc(&W, 256L * 8192 + (1 << 20));
-  hipMalloc(&sink, 64); hipMalloc(&cyc, 256 * 8);
+  hipMalloc(&sink, 64); hipMalloc(&cyc, 1024 * 8);
   hipMemset(A, 1, 256L * rowsA * lda); hipMemset(W, 1, 256L * 8192);
   // kb = K bytes per row per step: 64 (BK=32) for RB=64; 128 (BK=64) for RB=64/128
   // lda = 1024 B means K = 512 -> with kb=64 only 16 steps are distinct; wrap by using ksteps=16 per pass x4 via modulo is not
@@ -127,5 +128,13 @@ int main() {
     run<128, 0>("BK64 8x128B", A, ld, W, ld, 256, 256, ks64, 128, 2, 2, sink, cyc);
     run<64, 32>("BK32 16x64B + 32 mfma", A, ld, W, ld, 256, 256, ks32, 64, 2, 4, sink, cyc);
   }
+  // round 3: two workgroups per CU with 96-row frame tiles (22 KiB per 32-deep step each, three stages) against one with 192 rows
+  printf("---- one 192 + 256-row workgroup per CU vs two 96 + 256-row workgroups per CU (pitch 4096)\n");
+  g_grid = 256;
+  run<64, 0>("256+256 rows, 1 WG/CU", A, 4096, W, 4096, 256, 256, 64, 64, 2, 4, sink, cyc);
+  run<64, 32>("256+256 rows, 1 WG/CU + 32 mfma", A, 4096, W, 4096, 256, 256, 64, 64, 2, 4, sink, cyc);
+  g_grid = 512;
+  run<64, 0>("128+256 rows, 2 WG/CU", A, 4096, W, 4096, 128, 256, 64, 64, 4, 3, sink, cyc);
+  run<64, 16>("128+256 rows, 2 WG/CU + 16 mfma", A, 4096, W, 4096, 128, 256, 64, 64, 4, 3, sink, cyc);
   return 0;
 }
