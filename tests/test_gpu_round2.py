@@ -183,11 +183,11 @@ def test_full_size_properties_cfg3_cfg4(idx, B, L):
     """BASELINE configs[2] (WavLM-large + 2-layer BiLSTM H=512 + dilated stack, 64 x 10 s) and configs[3] per GPU (Whisper-small +
     the full default head, 64 x 30 s = 512 / 8 GPUs) at FULL size: multi-tile persistent GEMMs, attention_big (head_dim 512 / 384),
     four clip groups x 16 / 12 slice workgroups per direction in the recurrence; and configs[4] per GPU (Whisper-large-v3, all 32
-    layers, fp8 weights, 32 x 30 s = 256 / 8 GPUs).  No oracle run at this size (minutes of CPU):
-    the size-independent properties instead -- finite outputs, the decision rule frame by frame, bit-exact batch invariance
+    layers, fp8 weights, 32 x 30 s = 256 / 8 GPUs).  The oracle cannot label the whole batch (minutes of CPU): the size-independent
+    properties -- finite outputs, the decision rule frame by frame, bit-exact batch invariance
     (a clip labelled alone equals the same clip inside the batch of 64), determinism, and a clean status word."""
     cfg = synth.baseline_config(idx)
-    m, labels, _ = _build(cfg, 70, seed=70 + idx)
+    m, labels, _sd = _build(cfg, 70, seed=70 + idx)
     base = synth.make_batch(6000 + 100 * idx, 16, L, seed=70 + idx)
     wav = np.stack([np.roll(base[i % 16], 1231 * (i // 16)) * (1.0 - 0.05 * (i // 16)) for i in range(B)]).astype(np.float32)
     lang = (np.arange(B) % 2).astype(np.int64)
@@ -209,6 +209,36 @@ def test_full_size_properties_cfg3_cfg4(idx, B, L):
     again = m.label(x, lang, threshold=0.5, want_logits=True)
     assert torch.equal(again.logits, full.logits) and torch.equal(again.ids, full.ids)
     m.check(B, L)
+    # ... and the reference at the size that ships: the oracle labels ONE clip of the batch (row 17: second clip group of the recurrence,
+    # a rolled and scaled copy of a base clip) alone, at full length, all layers -- seconds of CPU -- and that row of the 64- / 32-clip
+    # forward is held to it with the fixed tau rule of test_gpu_model.py (tau = 0.4 * std / 6.5; for the fp8 config the target is the
+    # reference on the fp8-rounded checkpoint, as in test_baseline_config_5_fp8_weights_vs_oracle).  Batch invariance (above) ties every
+    # other row of the batch to the same arithmetic.
+    i = 17
+    sd_t = synth.round_weights_fp8(_sd) if cfg["model"].get("weight_dtype") == "fp8" else _sd
+    enc, arch = resolve_encoder_arch(cfg["model"])
+    lg, of = O.forward(torch.from_numpy(wav[i:i + 1]), torch.from_numpy(lang[i:i + 1]), O.to_torch_state_dict(sd_t), enc, arch,
+                       synth.head_config(cfg["model"]))
+    ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
+    err = (full.logits[i:i + 1].cpu() - lg).abs()
+    of_err = (full.offsets[i:i + 1].cpu() - of).abs()
+    std = float(lg.std())
+    tau = 0.4 * std / 6.5
+    safe = margin > tau
+    bad = int((full.argmax[i:i + 1].cpu().long() != arg_ref)[safe].sum())
+    try:
+        import json
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_stats.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=f"full_size_row_vs_oracle_cfg{idx + 1}", logit_std=std, tau=tau, logits_max=float(err.max()),
+                                    logits_mean=float(err.mean()), offsets_max=float(of_err.max()), safe_frac=float(safe.float().mean()),
+                                    argmax_bad=bad, argmax_all_mismatch=int((full.argmax[i:i + 1].cpu().long() != arg_ref).sum()),
+                                    frames=int(arg_ref.numel()))) + "\n")
+    except OSError:
+        pass
+    assert float(err.max()) <= 0.40 * max(1.0, std / 6.5) and float(err.mean()) <= 0.08 * max(1.0, std / 6.5), (float(err.max()), float(err.mean()), std)
+    assert float(of_err.max()) <= 0.02
+    assert bad == 0 and float(safe.float().mean()) >= 0.5
 
 
 def test_outlier_channels_through_the_folded_layernorm_path():

@@ -126,11 +126,23 @@ def main():
                 torch.cuda.synchronize()
                 times[n].append(e0.elapsed_time(e1) * 100)
         print(f"--- {name}  K={K} N={N}")
+        first_out = None
         for n, lib in libs.items():
             stamps.zero_()
             Cb.zero_()
             assert run(lib, True) == 0
             torch.cuda.synchronize()
+            # every build against the first one, whole output, over several launches (a race in a build shows as a difference)
+            if first_out is None:
+                first_out = Cb.clone()
+            else:
+                nd = 0
+                for _ in range(8):
+                    Cb.zero_()
+                    run(lib, False)
+                    torch.cuda.synchronize()
+                    nd += int((Cb.view(torch.int16) != first_out.view(torch.int16)).sum().item())
+                print(f"  {n:14s} elements differing from the first build's output over 8 launches: {nd}")
             out = Cb[lead + ridx].float()
             diff = ((out - ref).abs() / (ref.abs() + 1.0)).max().item()
             s = stamps.view(-1, 8).cpu().numpy().astype(np.int64)

@@ -72,16 +72,10 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 //   step is 8 KiB instead of 16 (one LDS-DMA piece per wave instead of two: 20 KiB per step instead of 28 -- the K loop is bound
 //   by exactly these bytes), fragments are read as 8 bytes and converted to bf16 in registers (v_cvt_pk_f32_fp8 +
 //   v_cvt_pk_bf16_f32, exact), the MFMA stays bf16 x bf16, the scale multiplies the accumulator in the epilogue.
-// MT = 3 (round 3): 96-row tiles, a three-stage ring and at most 128 registers, so that TWO workgroups share a CU (launch_stream
-//   starts 512 of them).  A tile's epilogue -- which the 192-row kernel cannot hide: both wave groups run it one after the other at every
-//   tile boundary, a third to a half of a K = 512 launch -- then runs under the OTHER workgroup's K loop; the K loop itself moves
-//   22 KiB per 96 x 256 x 32 step instead of 28 per 192 x 256 x 32 and is the slower one per FLOP, so this form is taken for short K only.
-template <int MT> struct StreamGeom { static constexpr int NST = MT == 3 ? 3 : SNST; static constexpr int WAVES_PER_EU = MT == 3 ? 4 : 2; };
 template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV, bool W8 = false>
-__global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   static_assert(!CONV || (MT == 6 && !RES && LNF == 0 && !STATS), "conv mode: 192-row tiles, plain epilogue");
   static_assert(!W8 || (!CONV && MT == 6), "fp8 weights: plain 192-row mode");
-  constexpr int NST = StreamGeom<MT>::NST;        // ring depth of this instantiation (stages)
   constexpr int BMV = MT * 32;                    // frame rows per tile
 #ifdef WFL_LAB_STB32
   constexpr int STB = 512 * SBK * 2;
@@ -91,12 +85,12 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
   constexpr int WOFF = CONV ? 0 : BMV * SBK * 2;
 #endif
   constexpr int AEXT = 224 * SBK * 2;             // CONV: extended frame tile (BMV + up to 32 taps - 1 rows), two of them
-  constexpr int AOFF = NST * STB;
+  constexpr int AOFF = SNST * STB;
   constexpr int NSTORE = (RES ? 4 : 2) * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around; a residual
                                                                   // launch always stores the hi and the lo half)
   constexpr int SROW = 4;                             // float2 slots per row of the statistics buffer (one per 256-column tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* stat_lds = (float*)(smem + NST * STB + (CONV ? 2 * AEXT : 0));  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
+  float* stat_lds = (float*)(smem + SNST * STB + (CONV ? 2 * AEXT : 0));  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,16 +114,14 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
 
   // ---- operand stream (prefetch cursor).  Frame row groups: MT = 8: waves load two each; MT = 6: waves 0-3 two, 4-7 one.
   // (CONV: the 14 row groups of the extended tile: waves 0-5 two each, 6-7 one)
-  // (MT = 3: the six row groups go to waves 0-5, one each; waves 6 and 7 stage weight pieces only)
-  const bool two_x = CONV ? wid < 6 : (MT == 8 || (MT == 6 && wid < 4));
-  const bool has_x = MT != 3 || wid < 6;
-  const int xg0 = CONV ? (wid < 6 ? wid * 2 : 12 + (wid - 6)) : (MT == 3 ? (wid < 6 ? wid : 0) : ((MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4)));
+  const bool two_x = CONV ? wid < 6 : (MT == 8 || wid < 4);
+  const int xg0 = CONV ? (wid < 6 ? wid * 2 : 12 + (wid - 6)) : ((MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4));
   const int ntaps = CONV ? p.K / p.cin : 1;
   const bf16_t* a_src[2];
   const bf16_t* w_src[2];
   const char* w8_src = nullptr;                     // W8: this lane's 16 source bytes of the wave's ONE weight piece (32 rows x 32 bytes)
   int pv = blockIdx.x, pkt = 0, issued = 0;
-  int islot = 0;                                    // ring slot of the next stage to issue (= issued % NST)
+  int islot = 0;                                    // ring slot of the next stage to issue (= issued % SNST)
   int ptap_k = 0;                                   // position inside the current tap (conv GEMMs), elements
   long pbase = 0;                                   // tap * tap_stride
   int pcc = 0, ptap = 0, pccg = 0;                  // CONV: channel chunk / tap being issued; chunks issued so far (buffer parity)
@@ -160,7 +152,7 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
   auto issue_stage = [&]() __attribute__((always_inline)) {                        // the DMA of stage (pv, pkt); advances the position inside the tile
     if (CONV) {
       char* base = smem + islot * STB;
-      islot = islot + 1 == NST ? 0 : islot + 1;
+      islot = islot + 1 == SNST ? 0 : islot + 1;
       if (ptap == 0) {                               // first tap of a channel chunk: its extended frame tile rides along
         char* ab = smem + AOFF + (pccg & 1) * AEXT;
         sglds(a_src[0] + pcc * SBK, ab + xg0 * 1024);
@@ -175,8 +167,8 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
     }
     const long koff = pbase + ptap_k;
     char* base = smem + islot * STB;
-    islot = islot + 1 == NST ? 0 : islot + 1;
-    if (has_x) sglds(a_src[0] + koff, base + xg0 * 1024);
+    islot = islot + 1 == SNST ? 0 : islot + 1;
+    sglds(a_src[0] + koff, base + xg0 * 1024);
     if (two_x) sglds(a_src[1] + koff, base + xg0 * 1024 + 1024);
     if (W8) {
       sglds((const bf16_t*)(w8_src + pkt * SBK), base + WOFF + wid * 1024);
@@ -199,8 +191,8 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
     constexpr int NDC = decltype(ndc_c)::value;
     const long koff = pbase + ptap_k;
     char* base = smem + islot * STB;
-    islot = islot + 1 == NST ? 0 : islot + 1;
-    if (has_x) sglds(a_src[0] + koff, base + xg0 * 1024);
+    islot = islot + 1 == SNST ? 0 : islot + 1;
+    sglds(a_src[0] + koff, base + xg0 * 1024);
     if (two_x) sglds(a_src[1] + koff, base + xg0 * 1024 + 1024);
     if (W8) {
       if (NDC == 0) sglds((const bf16_t*)(w8_src + pkt * SBK), base + WOFF + wid * 1024);
@@ -236,17 +228,17 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
     // DMA pieces per wave and stage: CONV two weight pieces (the extended frame tile's pieces, one stage in `taps`, are not counted:
     // a smaller count only waits for more, and they are issued taps - 3 steps before their first read); else two / one frame
     // pieces + the weight pieces
-    constexpr int L2X = CONV ? 2 : (W8 ? 3 : 4), L1X = CONV ? 2 : (W8 ? 2 : 3), L0X = 2;
-    static_assert(NST >= 3 && NST <= 6, "ring depth");
+    constexpr int L2X = CONV ? 2 : (W8 ? 3 : 4), L1X = CONV ? 2 : (W8 ? 2 : 3);
+    static_assert(SNST >= 3 && SNST <= 6, "ring depth");
 #define WFL_WAITY(L)                                                                              \
     do {                                                                                          \
-      if (NST >= 6 && younger >= 4) { if (with_stores) wait_vm<4 * (L) + NSTORE>(); else wait_vm<4 * (L)>(); }       \
-      else if (NST >= 5 && younger >= 3) { if (with_stores) wait_vm<3 * (L) + NSTORE>(); else wait_vm<3 * (L)>(); }  \
+      if (SNST >= 6 && younger >= 4) { if (with_stores) wait_vm<4 * (L) + NSTORE>(); else wait_vm<4 * (L)>(); }       \
+      else if (SNST >= 5 && younger >= 3) { if (with_stores) wait_vm<3 * (L) + NSTORE>(); else wait_vm<3 * (L)>(); }  \
       else if (younger >= 2) { if (with_stores) wait_vm<2 * (L) + NSTORE>(); else wait_vm<2 * (L)>(); }              \
       else if (younger == 1) { if (with_stores) wait_vm<(L) + NSTORE>(); else wait_vm<(L)>(); }                      \
       else { if (with_stores) wait_vm<NSTORE>(); else wait_vm<0>(); }                                                \
     } while (0)
-    if (CONV || two_x) WFL_WAITY(L2X); else if (has_x) WFL_WAITY(L1X); else WFL_WAITY(L0X);
+    if (CONV || two_x) WFL_WAITY(L2X); else WFL_WAITY(L1X);
 #undef WFL_WAITY
   };
 
@@ -307,7 +299,7 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
     }
     // residual hi + lo halves: a ring of three 16-frame tiles in flight (all six at once would not fit the register file next
     // to the accumulators); tile u + 3 is requested as soon as tile u has been consumed
-    constexpr int RING = MT == 3 ? 2 : 3;            // (MT = 3 lives in 128 registers)
+    constexpr int RING = 3;
     bf16x8 rr[RES ? RING : 1][2], rl[RES ? RING : 1][2];
     const bf16_t* res_lo = p.res_lo ? p.res_lo : p.res;     // no low half: read the high one again and scale it away
     const float lo_scale = p.res_lo ? 1.f : 0.f;
@@ -434,7 +426,7 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
   if (STATS && tid < 2) ((unsigned*)(stat_lds + 8 * (MT * 16) * 2))[tid] = 0;   // the groups' arrival counters
   // ---- prologue: three stages in flight, stage 0 landed, group 1 one barrier behind
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t) prefetch_one();
+  for (int t = 0; t < SNST - 1; ++t) prefetch_one();
   wait_stage(0, false);
   __builtin_amdgcn_s_barrier();
   SSTAMP(1);
@@ -443,7 +435,7 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
 #define SSB() __builtin_amdgcn_sched_barrier(0)
   bf16x8 fw[4], fx[MT];
   int s = 0;                                         // global K-step counter
-  int rslot = 0;                                     // its ring slot (= s % NST)
+  int rslot = 0;                                     // its ring slot (= s % SNST)
   int ctap = 0, ccg = 0;                              // CONV: tap of the step being computed; chunks finished (buffer parity)
   auto read_frags = [&]() __attribute__((always_inline)) {
     const char* sb = smem + rslot * STB;
@@ -522,39 +514,39 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
     int m0, n0;
     tile_of(tv, m0, n0);
     const bool last_tile = tv + G >= ntiles;
-    // One K step, general form: used for the first NST - 2 steps of a tile (the previous tile's epilogue and its stores sit in
-    // the vmcnt queue: the stages issued before them are 0 .. NST - 2) and the last NST (the stream crosses into the next tile,
+    // One K step, general form: used for the first SNST - 2 steps of a tile (the previous tile's epilogue and its stores sit in
+    // the vmcnt queue: the stages issued before them are 0 .. SNST - 2) and the last SNST (the stream crosses into the next tile,
     // or ends).
     auto step_general = [&](int kt, auto first_c) __attribute__((always_inline)) {
       if (decltype(first_c)::value && have_prev) epilogue(pm0, pn0);
       read_frags();
       prefetch_one();
-      if (grp) wait_stage(s + 1, have_prev && kt < NST - 2);
+      if (grp) wait_stage(s + 1, have_prev && kt < SNST - 2);
       __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
       SSB();
       mma_all(std::integral_constant<int, 0>{});
       if (LNF == 1 && kt == nk - 1) ln_publish();
       SSB();
-      if (!grp) wait_stage(s + 1, have_prev && kt < NST - 2);
+      if (!grp) wait_stage(s + 1, have_prev && kt < SNST - 2);
       if (LNF == 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // the statistics are in LDS before the barrier
       if (LNF == 1 || !(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
       SSB();
       ++s;
-      rslot = rslot + 1 == NST ? 0 : rslot + 1;
+      rslot = rslot + 1 == SNST ? 0 : rslot + 1;
     };
-    // Steady state, kt in [NST - 2, nk - NST - 1]: the stage being issued (kt + NST - 1) and the ones awaited next lie inside
-    // this tile and nothing but operand DMA is in the queue, so the waits are constants: NST - 2 stages stay in flight behind the
+    // Steady state, kt in [SNST - 2, nk - SNST - 1]: the stage being issued (kt + SNST - 1) and the ones awaited next lie inside
+    // this tile and nothing but operand DMA is in the queue, so the waits are constants: SNST - 2 stages stay in flight behind the
     // awaited one.  One copy per wave group (no per-step branches).
     auto steps_steady = [&](auto grp_c) __attribute__((always_inline)) {
       constexpr bool GRP1 = decltype(grp_c)::value;
-      constexpr int NL = CONV ? 2 : (MT == 3 ? 3 : ((MT == 8 || !GRP1) ? (W8 ? 3 : 4) : (W8 ? 2 : 3)));   // (MT = 3: waves with a frame piece)
+      constexpr int NL = CONV ? 2 : ((MT == 8 || !GRP1) ? (W8 ? 3 : 4) : (W8 ? 2 : 3));
 #ifndef WFL_DMA_IN_C
 #define WFL_DMA_IN_C 0     // (measured neutral at 1 and 2: tools/gemm_lab.py)
 #endif
       constexpr int NDC = CONV ? 0 : (W8 ? (WFL_DMA_IN_C > 1 ? 1 : WFL_DMA_IN_C) : WFL_DMA_IN_C);   // weight pieces issued inside the C slot
       const std::integral_constant<int, NDC> ndc_c{};
-      for (int kt = NST - 2; kt <= nk - NST - 1; ++kt) {
+      for (int kt = SNST - 2; kt <= nk - SNST - 1; ++kt) {
 #ifndef WFL_ABL_NOLDS          // diagnostic builds (tools/gemm_lab.py): no fragment reads / no operand DMA in the steady loop
         read_frags();
 #endif
@@ -564,24 +556,24 @@ __global__ __launch_bounds__(512, StreamGeom<MT>::WAVES_PER_EU) void gemm_stream
         ++issued; ++pkt; if (CONV) { if (++ptap == ntaps) { ptap = 0; ++pcc; ++pccg; } }
 #endif
         // group 1 waits before the barrier: stage kt+2 is out in full, stage kt+3 only with its L-slot pieces so far
-        if (GRP1) { if (MT != 3 || has_x) wait_vm<(NST - 2) * NL - NDC>(); else wait_vm<(NST - 2) * 2>(); }
+        if (GRP1) wait_vm<(SNST - 2) * NL - NDC>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         SSB();
         mma_all(ndc_c);
         SSB();
-        if (!GRP1) wait_vm<(NST - 2) * NL>();
+        if (!GRP1) wait_vm<(SNST - 2) * NL>();
         __builtin_amdgcn_s_barrier();
         SSB();
         ++s;
-        rslot = rslot + 1 == NST ? 0 : rslot + 1;
+        rslot = rslot + 1 == SNST ? 0 : rslot + 1;
       }
     };
     step_general(0, std::true_type{});
 #pragma unroll
-    for (int kt = 1; kt < NST - 2; ++kt) step_general(kt, std::false_type{});
+    for (int kt = 1; kt < SNST - 2; ++kt) step_general(kt, std::false_type{});
     if (grp) steps_steady(std::true_type{}); else steps_steady(std::false_type{});
-    for (int kt = nk - NST > NST - 2 ? nk - NST : NST - 2; kt < nk; ++kt) step_general(kt, std::false_type{});
+    for (int kt = nk - SNST > SNST - 2 ? nk - SNST : SNST - 2; kt < nk; ++kt) step_general(kt, std::false_type{});
     pm0 = m0; pn0 = n0;
     have_prev = true;
   }
@@ -599,8 +591,7 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
 #ifdef WFL_LAB_STB32
   constexpr int lds = SNST * 512 * SBK * 2 + 8 * (MT * 16) * 2 * 4 + 64;
 #else
-  constexpr int NST = StreamGeom<MT>::NST;
-  constexpr int lds = (CONV ? NST * 256 * SBK * 2 + 2 * 224 * SBK * 2 : NST * (BMV * SBK * 2 + 256 * SBK * (W8 ? 1 : 2))) + 8 * (MT * 16) * 2 * 4 + 64;
+  constexpr int lds = (CONV ? SNST * 256 * SBK * 2 + 2 * 224 * SBK * 2 : SNST * (BMV * SBK * 2 + 256 * SBK * (W8 ? 1 : 2))) + 8 * (MT * 16) * 2 * 4 + 64;
 #endif
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
   auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV, W8>;
@@ -609,8 +600,7 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
   g_wfl_gemm_kernel_id = CONV ? 6 : (W8 ? 7 : (MT == 6 ? 1 : 5));
-  constexpr int max_wgs = MT == 3 ? 2 * SNCU : SNCU;          // persistent workgroups: one per CU, two of the 96-row form
-  hipLaunchKernelGGL(k, dim3(tiles < max_wgs ? tiles : max_wgs), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -620,19 +610,11 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
 // 192 rows).  WFL_GEMM_BM=256 still selects it for experiments.
 template <int ACT, bool RES, int LNF, bool STATS = false>
 static int launch_stream_mt(const GemmArgs& a, hipStream_t s) {
-  static int forced = -1, mt3_maxk = -1;
-  if (forced < 0) {
-    const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0;
-    // 96-row tiles, two workgroups per CU (the note at the kernel), for K up to this many (0: never).  Chosen by K alone -- never by the
-    // batch size -- although the two forms give bit-identical results (same K order per output element).
-    const char* k3 = getenv("WFL_GEMM_MT3_MAXK"); mt3_maxk = k3 ? atoi(k3) : 1024;
-  }
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0; }
 #ifdef WFL_STREAM_MT8
   if (forced == 256) return launch_stream<ACT, 8, RES, LNF, STATS>(a, s);
 #endif
-  if constexpr (LNF != 1) {
-    if (forced == 96 || (forced == 0 && a.K <= mt3_maxk)) return launch_stream<ACT, 3, RES, LNF, STATS>(a, s);
-  }
   return launch_stream<ACT, 6, RES, LNF, STATS>(a, s);
 }
 
