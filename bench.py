@@ -333,15 +333,18 @@ def main():
         roof = None
         if prof:
             acts = {0: 0, 1: 1, 2: 2, 3: 3}
+            fp8_act = str(m.get("weight_dtype", "bf16")) == "fp8" and os.environ.get("WFL_FP8_ACT", "1") != "0"
 
             def kname(key):
                 """rocprofv3 kernel name of the template instantiation behind a profile key (model.hip: Runner::gemm)."""
                 act, glu, f32, res, kid = key & 3, bool(key & 4), bool(key & 8), bool(key & 16), (key >> 5) & 7
                 lnf, stats = (key >> 8) & 3, bool(key & 1024)
                 tf = lambda b: "true" if b else "false"
-                if kid in (1, 5, 6, 7):               # 6 = the tap-stationary conv mode, 7 = fp8 (e4m3) weights
-                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s, %s>" % (acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats),
-                                                                               tf(kid == 6), tf(kid == 7))
+                if kid in (1, 5, 6, 7):               # 6 = the tap-stationary conv mode, 7 = fp8: e4m3 weights (W8) or both operands e4m3 (A8)
+                    a8 = kid == 7 and fp8_act
+                    return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s, %s, %s, %s>" % (
+                        acts[act], 8 if kid == 5 else 6, tf(res), lnf, tf(stats), tf(kid == 6), tf(kid == 7 and not a8), tf(a8),
+                        tf(a8 and act == 1 and not res))
                 if kid in (2, 3):
                     return "gemm256_kernel<%d, %s, %s, %d>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
                 return "gemm_bf16_kernel<%d, %s, %s>" % (acts[act], tf(glu), tf(f32))
@@ -358,7 +361,8 @@ def main():
                 breakdown[OTHER_KEYS.get(p["key"], str(p["key"]))] = p["ms"] / args.steps
             roof = {
                 "bound": "mfma",
-                "kernel": "bf16 MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations)",
+                "kernel": "MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations; bf16, and for "
+                          "fp8 models the non-scaled fp8 MFMA, which issues at the bf16 rate: same 2.5 PF roof)",
                 "timing": "HIP events (launch stream) around every launch of a second pass over the same %d steps, run right after the "
                           "timed region, one batch at a time so that no other kernel shares the GPU with the one being timed "
                           "(%.3f ms/step with the events in)" % (args.steps, eager_ms),
@@ -383,7 +387,9 @@ def main():
             "metric": "audio_seconds_labeled_per_sec_per_node", "value": audio_s / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (fp8 e4m3 encoder weights)" if str(m.get("weight_dtype", "bf16")) == "fp8" else "bf16", "data": "synthetic",
+            "dtype": ("fp8 (e4m3 weights and activations in the encoder's GEMMs, v_mfma_f32_16x16x32_fp8_fp8; bf16 elsewhere)"
+                      if os.environ.get("WFL_FP8_ACT", "1") != "0" else "bf16 (fp8 e4m3 encoder weights)")
+                     if str(m.get("weight_dtype", "bf16")) == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": ("default config.yaml head: " if args.full_head else "BASELINE configs[%d]: " % args.config_index)
                        + "%s + %s%d Conformer blocks%s, %d x %g s clips per GPU" % (
                 enc_name, "%d-layer BiLSTM + " % m["bilstm_num_layer"] if m["enable_bilstm"] else "", m["num_conformer_layers"],

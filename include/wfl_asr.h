@@ -227,6 +227,34 @@ int32_t wfl_host_load_wavs(const char* const* paths, int32_t n, float* out, int6
 int32_t wfl_host_load_wav_chunks(const char* path, int32_t target_sr, int64_t chunk_samples, float* out, int64_t ld, int32_t max_rows,
                                  int32_t* n_rows, int32_t* lens, int32_t* sample_rate);
 
+/* ---- audio ingest on the GPU (round 3): a file that is not at the model's rate no longer costs host cores.
+ * wfl_host_read_pcm16 copies the 16-bit PCM samples of `n` WAV files as they are (interleaved, 1 or 2 channels) into rows
+ * out + i * ld of a (pinned) int16 buffer -- status 0 ok, 1 not 16-bit PCM, 2 more than two channels, 3 more than cap_samples values,
+ * 4 cannot open.  wfl_resample_pcm16 (device pointers, one HIP stream) turns B such rows of ONE sample rate into float32 rows ready
+ * for wfl_forward: decode ((l + r) / 2 for two channels), band-limited sinc resampling to new_sr -- torchaudio.functional.resample's
+ * published algorithm in float64 (/root/reference/infer.py:217-220; parity with torchaudio UNPINNED: library absent), bit-identical to
+ * wfl_host_load_wav_chunks -- and whole-clip peak normalisation x / (max|x| + 1e-8) in float64 (infer.py:234-235).  Row b of `out`
+ * receives min(ceil(len_b * new_sr / orig_sr), out_cap) samples followed by zeros up to out_cap; clips that come out longer than
+ * out_cap (= 30 s: they would be cut into chunks) belong to wfl_host_load_wav_chunks. */
+int32_t wfl_host_read_pcm16(const char* const* paths, int32_t n, int16_t* out, int64_t ld, int64_t cap_samples, int32_t* n_frames,
+                            int32_t* channels, int32_t* sample_rates, int32_t* status, int32_t threads);
+int64_t wfl_resample_workspace_bytes(int32_t B, int32_t out_cap);
+int32_t wfl_resample_pcm16(const int16_t* pcm, int64_t ld_in, const int32_t* n_in, const int32_t* channels, int32_t B, int32_t orig_sr,
+                           int32_t new_sr, float* out, int64_t ld_out, int32_t out_cap, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+
+/* ---- boundary-snapping features on the GPU (round 3; /root/reference/correct_label.py:15-24, the step the
+ * reference's notebook runs after inference): for B clips of up to L samples at 16 kHz (device pointers, one HIP stream),
+ *   flux[b][t]    spectral flux of |librosa.stft(y, n_fft=512, hop_length=160)| (flux[b][0] = 0),
+ *   mfcc[b][c][t] librosa.feature.mfcc(y, sr=16000, n_mfcc=13, hop_length=160): n_fft 2048, 128 Slaney mel bands, dB with top_db 80,
+ *                 orthonormal DCT-II,
+ * t < F = 1 + L / 160.  mel_w [128][1025] and dct [13][128] are the caller's (wfl-asr_amd/correct_label.py builds them; its numpy
+ * restatement of the same features is what tests hold this to).  Restated from librosa's documented definitions: parity with librosa
+ * itself is UNPINNED (library absent, the reference holds no fixtures). */
+int64_t wfl_boundary_workspace_bytes(int32_t B, int32_t L);
+int32_t wfl_boundary_features(const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L, const float* mel_w,
+                              const float* dct, float* flux, float* mfcc, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

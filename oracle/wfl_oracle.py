@@ -130,9 +130,28 @@ def _linear(x, sd, p):
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
-def whisper_encoder(feats: torch.Tensor, sd: dict, heads: int, layers: int, prefix: str = "encoder.") -> torch.Tensor:
+def _e4m3(x: torch.Tensor) -> torch.Tensor:
+    """Round to OCP e4m3 (fn) and back: nearest even, |x| <= 448 expected."""
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def e4m3_rows(x: torch.Tensor) -> torch.Tensor:
+    """x as the MI355X path's fp8 GEMMs see it: every row (last dim) scaled so that its maximum is 448, rounded to e4m3, scaled back
+    (csrc/norm.hip, rows_fp8_kernel)."""
+    mx = x.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(mx > 0, mx * (1.0 / 448.0), torch.ones_like(mx))
+    return _e4m3(x * (1.0 / scale)) * scale
+
+
+def whisper_encoder(feats: torch.Tensor, sd: dict, heads: int, layers: int, prefix: str = "encoder.", act_fp8: bool = False,
+                    ff_scale: float = 8.0, att_scale: float = 8.0) -> torch.Tensor:
     """[B, n_mels, 2T] -> [B, T, d].  HF modeling_whisper.py:618-642 (stem 618-625, layers 627-640,
-    final LN 642); layer 391-407; attention 309 (q scaled), 332-333 (k no bias), SDPA scaling 1.0."""
+    final LN 642); layer 391-407; attention 309 (q scaled), 332-333 (k no bias), SDPA scaling 1.0.
+    act_fp8 (not the reference: the target of the fp8 x fp8 build, BASELINE configs[4]): the four GEMM inputs of every layer -- both
+    LayerNorm outputs per row, the attention context (head size 64: fixed scale att_scale, else per row) and fc1's GELU output (fixed
+    scale ff_scale) -- rounded to e4m3 exactly
+    where csrc/model.hip rounds them; the checkpoint is expected to be the fp8-rounded one (synth.round_weights_fp8)."""
+    rows8 = e4m3_rows if act_fp8 else (lambda t: t)
     p = prefix
     x = F.gelu(F.conv1d(feats, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
     x = F.gelu(F.conv1d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], stride=2, padding=1))
@@ -141,15 +160,19 @@ def whisper_encoder(feats: torch.Tensor, sd: dict, heads: int, layers: int, pref
     hd = d // heads
     for i in range(layers):
         lp = f"{p}layers.{i}."
-        h = _ln(x, sd, lp + "self_attn_layer_norm")
+        h = rows8(_ln(x, sd, lp + "self_attn_layer_norm"))
         q = (_linear(h, sd, lp + "self_attn.q_proj") * hd ** -0.5).view(B, T, heads, hd).transpose(1, 2)
         k = _linear(h, sd, lp + "self_attn.k_proj").view(B, T, heads, hd).transpose(1, 2)
         v = _linear(h, sd, lp + "self_attn.v_proj").view(B, T, heads, hd).transpose(1, 2)
         a = torch.softmax(q @ k.transpose(2, 3), dim=-1) @ v
         a = a.transpose(1, 2).reshape(B, T, d)
+        if act_fp8:
+            a = _e4m3(a * att_scale) * (1.0 / att_scale) if hd == 64 else e4m3_rows(a)
         x = x + _linear(a, sd, lp + "self_attn.out_proj")
-        h = _ln(x, sd, lp + "final_layer_norm")
+        h = rows8(_ln(x, sd, lp + "final_layer_norm"))
         h = F.gelu(_linear(h, sd, lp + "fc1"))
+        if act_fp8:
+            h = _e4m3(h * ff_scale) * (1.0 / ff_scale)
         x = x + _linear(h, sd, lp + "fc2")
     return _ln(x, sd, p + "layer_norm")
 
@@ -369,11 +392,11 @@ def to_torch_state_dict(sd_np: dict) -> dict:
 
 
 @torch.no_grad()
-def forward(wav: torch.Tensor, lang_id, sd: dict, enc: str, arch, hc: dict, return_hidden: bool = False):
-    """ref model.py:148-194 BIOPhonemeTagger.forward (encoder_type whisper | wavlm | none)."""
+def forward(wav: torch.Tensor, lang_id, sd: dict, enc: str, arch, hc: dict, return_hidden: bool = False, act_fp8: bool = False):
+    """ref model.py:148-194 BIOPhonemeTagger.forward (encoder_type whisper | wavlm | none).  act_fp8: see whisper_encoder."""
     if enc == "whisper":
         feats = whisper_log_mel(wav, arch.n_mels, arch.max_positions * 2 * arch.hop, arch.n_fft, arch.hop)
-        hidden = whisper_encoder(feats, sd, arch.heads, arch.layers)
+        hidden = whisper_encoder(feats, sd, arch.heads, arch.layers, act_fp8=act_fp8)
     elif enc == "wavlm":
         hidden = wavlm_encoder(wavlm_normalize(wav.to(torch.float32), arch.do_normalize), sd, arch)
     elif enc == "none":

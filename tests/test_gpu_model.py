@@ -59,11 +59,11 @@ def _build(cfg, n_phonemes, seed):
     return m, labels, sd_np
 
 
-def _oracle(cfg, labels, sd_np, wav, lang):
+def _oracle(cfg, labels, sd_np, wav, lang, act_fp8=False):
     enc, arch = resolve_encoder_arch(cfg["model"])
     sd = O.to_torch_state_dict(sd_np)
     lg, of, hid = O.forward(torch.from_numpy(wav), None if lang is None else torch.from_numpy(lang), sd, enc, arch,
-                            synth.head_config(cfg["model"]), return_hidden=True)
+                            synth.head_config(cfg["model"]), return_hidden=True, act_fp8=act_fp8)
     return lg, of, hid
 
 
@@ -340,13 +340,17 @@ def test_baseline_configs_3_and_4_vs_oracle(idx, B, L):
 
 @pytest.mark.parametrize("case", ["large_v3_4l", "base_6l"])
 def test_baseline_config_5_fp8_weights_vs_oracle(case):
-    """BASELINE configs[4]: Whisper-large-v3 encoder with fp8 weights (model.weight_dtype: fp8 -- q|k|v, out_proj, fc1, fc2 of every
-    layer as OCP e4m3 with one scale per output channel, converted to bf16 in registers in front of the bf16 MFMA), linear head.
+    """BASELINE configs[4]: Whisper-large-v3 encoder in fp8 (model.weight_dtype: fp8), linear head.  Since round 3 the four GEMMs of
+    every layer run on v_mfma_f32_16x16x32_fp8_fp8: weights e4m3 with one scale per output channel (round 2), activations e4m3 too
+    -- both LayerNorm outputs and the attention context with one scale per row, fc1's GELU output with a fixed scale.
     "large_v3_4l" is the real geometry (128 mel bins, d = 1280, 20 heads, FFN 5120) with 4 of the 32 layers so that the CPU oracle
-    finishes in seconds; "base_6l" runs ALL layers of a smaller fp8 encoder (Whisper-base dims) so error growth through a whole
-    stack is covered too.  Two targets, as for bf16: the oracle on the fp8-rounded checkpoint (synth.round_weights_fp8: what is left
-    is activation rounding -- target A's tolerances) and the oracle on the checkpoint as given (an e4m3 weight carries 3 mantissa
-    bits, 32x coarser than bf16: reported, bounded loosely)."""
+    finishes in seconds (tests/test_gpu_round2.py holds one row of the full 32-layer, 32-clip forward to the oracle too); "base_6l"
+    runs ALL layers of a smaller fp8 encoder (Whisper-base dims).  Three targets, all outputs of the oracle = the reference's arithmetic:
+      A8  the fp8-rounded checkpoint with the activations rounded to e4m3 where the build rounds them (oracle act_fp8);
+      W8  the fp8-rounded checkpoint, exact activations;
+      F32 the checkpoint as given.
+    The yardstick is the oracle's own A8 - W8 distance (see below): the build must not be further from A8 than 1.25 x that distance
+    (it measures 1.03 x), and tag indices must agree wherever the reference's top-2 margin exceeds 4 tau (8 tau against F32)."""
     cfg = synth.baseline_config(4)
     assert cfg["model"]["weight_dtype"] == "fp8"
     if case == "large_v3_4l":
@@ -360,25 +364,72 @@ def test_baseline_config_5_fp8_weights_vs_oracle(case):
     wav = synth.make_batch(905, B, L, seed=45)
     lang = np.zeros(B, np.int64)
     out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True, want_hidden=True)
-    for target, sd_t in (("fp8_weights", synth.round_weights_fp8(sd_np)), ("fp32_weights", sd_np)):
-        lg, of, hid = _oracle(cfg, labels, sd_t, wav, lang)
+    m.check(B, L)
+    sd8 = synth.round_weights_fp8(sd_np)
+    refs = {t: _oracle(cfg, labels, sd_t, wav, lang, act_fp8=a8) for t, sd_t, a8 in (("A8", sd8, True), ("W8", sd8, False), ("F32", sd_np, False))}
+    # What the FORMAT costs, measured inside the reference's own arithmetic: the distance between the oracle with and without e4m3
+    # activations.  Rounding to 3 mantissa bits is chaotic -- a relative input change of 1e-3 moves the A8 oracle's own output by as
+    # much as this distance (an e4m3 step is 6-12 % of a value, so a bf16-sized difference in a LayerNorm output flips ~3 % of the
+    # roundings, and a flipped rounding is a whole step) -- so no fp8 build can sit closer to the A8 oracle than about this distance.
+    fmt_h = (refs["A8"][2] - refs["W8"][2]).abs()
+    fmt_l = (refs["A8"][0] - refs["W8"][0]).abs()
+    for target, tmul in (("A8", 4.0), ("W8", 4.0), ("F32", 8.0)):
+        lg, of, hid = refs[target]
         h_err = (out.hidden.cpu() - hid).abs()
         ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
         err = (out.logits.cpu() - lg).abs()
-        tau = (TAU if target == "fp8_weights" else 4 * TAU) * float(lg.std()) / 6.5
+        tau = tmul * TAU * float(lg.std()) / 6.5
         safe = margin > tau
         bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
         _note(f"cfg5_fp8_{case}_{target}", hidden_max=h_err.max(), hidden_mean=h_err.mean(), logit_std=lg.std(), tau=tau,
               logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
               safe_frac=safe.float().mean(), argmax_bad=bad, argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()),
-              frames=int(arg_ref.numel()))
-        if target == "fp8_weights":
-            assert h_err.max() <= 0.08 and h_err.mean() <= 0.012
-            assert err.max() <= 0.40 and err.mean() <= 0.08
-            assert (out.offsets.cpu() - of).abs().max() <= 0.02
+              frames=int(arg_ref.numel()), format_hidden_mean=fmt_h.mean(), format_logits_mean=fmt_l.mean(), format_logits_max=fmt_l.max())
+        if target == "A8":       # the build adds nothing of its own to what the format costs
+            assert h_err.mean() <= 1.25 * fmt_h.mean() and err.mean() <= 1.25 * fmt_l.mean(), (float(h_err.mean()), float(fmt_h.mean()), float(err.mean()), float(fmt_l.mean()))
+            assert err.max() <= 1.5 * fmt_l.max(), (float(err.max()), float(fmt_l.max()))
+        elif target == "W8":     # two independent roundings of the same size: sqrt(2) of one
+            assert h_err.mean() <= 1.7 * fmt_h.mean() and err.mean() <= 1.7 * fmt_l.mean(), (float(h_err.mean()), float(err.mean()))
         else:
-            assert h_err.mean() <= 0.08 and err.mean() <= 0.6
-        assert bad == 0
+            assert h_err.mean() <= 0.15 and err.mean() <= 1.2
+        assert (out.offsets.cpu() - of).abs().max() <= 0.08
+        assert bad == 0, (target, bad)
+        assert safe.float().mean() >= (0.2 if target == "F32" else 0.4)
+
+
+def test_fp8_weights_with_bf16_activations_is_still_there(monkeypatch):
+    """WFL_FP8_ACT=0: round 2's form of the fp8 build (e4m3 weights converted in registers, bf16 activations, bf16 MFMA) stays
+    selectable and stays within round 2's tolerances against the oracle on the fp8-rounded checkpoint."""
+    monkeypatch.setenv("WFL_FP8_ACT", "0")
+    cfg = synth.baseline_config(4)
+    cfg["model"]["whisper_model"] = "local/whisper-base-fp8"
+    cfg["model"]["encoder_arch"] = dict(d_model=512, layers=6, heads=8, ffn=2048, n_mels=80, max_positions=1500)
+    import subprocess, sys, textwrap
+    # (the switch is read once per process: a child process)
+    code = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, torch
+        from oracle import wfl_oracle as O
+        from wfl_asr_amd import synth
+        from wfl_asr_amd.archs import resolve_encoder_arch
+        from wfl_asr_amd.tagger import BIOPhonemeTagger
+        cfg = json.loads(%r)
+        labels = synth.make_labels(70)
+        sd_np = synth.make_state_dict(cfg, len(labels), seed=45)
+        m = BIOPhonemeTagger(cfg, labels); m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}); m.to("cuda").eval()
+        wav = synth.make_batch(905, 1, 160000, seed=45)
+        out = m.label(torch.from_numpy(wav).cuda(), np.zeros(1, np.int64), threshold=0.5, want_logits=True)
+        enc, arch = resolve_encoder_arch(cfg["model"])
+        lg, of = O.forward(torch.from_numpy(wav), torch.zeros(1, dtype=torch.long), O.to_torch_state_dict(synth.round_weights_fp8(sd_np)), enc, arch,
+                           synth.head_config(cfg["model"]))
+        err = (out.logits.cpu() - lg).abs()
+        print("RESULT", float(err.max()), float(err.mean()))
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), json.dumps(cfg))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, WFL_FP8_ACT="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    mx, mean = [float(v) for v in r.stdout.split("RESULT")[1].split()[:2]]
+    assert mx <= 0.40 and mean <= 0.08, (mx, mean)
 
 
 def test_graph_replay_is_bit_identical():

@@ -29,9 +29,11 @@ def main():
                     "Labeler's own batch size and batches in flight; prints the end-to-end rate only")
     ap.add_argument("--rate", type=int, default=16000, help="sample rate of the files on disk (other than 16000: every file takes the "
                     "general ingest path -- decode, resample, chunk -- and the end-to-end rate is printed alone)")
+    ap.add_argument("--wavlm", action="store_true", help="BASELINE configs[2] (WavLM-large + 2-layer BiLSTM + dilated stack) on files of "
+                    "6-10 s: the ragged by-length loop (Labeler._forward_items_by_length); prints the end-to-end rate only")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="wfl_e2e_")
-    cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(1)
+    cfg = synth.baseline_config(2) if args.wavlm else (synth.base_config("whisper") if args.full_head else synth.baseline_config(1))
     cfg["output"] = {"save_dir": os.path.join(d, "save")}
     cfg["postprocess"] = {"median_filter": 3, "merge_segments": "right", "confidence_threshold": 0.5}
     cfg.setdefault("data", {})["sample_rate"] = 16000
@@ -48,11 +50,24 @@ def main():
     paths = []
     if args.rate != 16000:
         base = [A.resample(b.astype(np.float64), 16000, args.rate).astype(np.float32) for b in base]
+    secs = []
     for i in range(args.files):
         p = os.path.join(wavs, f"{i:04d}.wav")
-        A.write_wav(p, base[i % 8], args.rate)
+        n = len(base[i % 8]) if not args.wavlm else int(args.rate * (6.0 + 4.0 * ((i * 37) % 101) / 100.0))     # 6 .. 10 s
+        A.write_wav(p, base[i % 8][:n], args.rate)
+        secs.append(n / args.rate)
         paths.append(p)
-    lab = I.Labeler(cfg, sd, "cuda", batch_size=None if args.full_head else 16)
+    lab = I.Labeler(cfg, sd, "cuda", batch_size=None if (args.full_head or args.wavlm) else 16)
+    if args.wavlm:
+        lab.label_files(paths[:2 * lab.batch_size], lang_id=0, confidence_threshold=0.5, verbose=False)      # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = lab.label_files(paths, lang_id=0, confidence_threshold=0.5, verbose=False)
+        t_all = time.perf_counter() - t0
+        print(f"WavLM-large + BiLSTM + dilated (BASELINE configs[2]) | files {len(paths)} x 6-10 s at {args.rate} Hz | rows per forward {lab.batch_size}, "
+              f"batches in flight {lab.n_inflight} | label_files end to end {1e3 * t_all / len(paths):.2f} ms/file = {sum(secs) / t_all:.0f} audio-s/s; "
+              f"segments/file {np.mean([len(o) for o in out]):.0f}")
+        return
     lab.label_files(paths[:4 * lab.batch_size], lang_id=0, confidence_threshold=0.5, verbose=False)      # warm-up
     torch.cuda.synchronize()
     if args.full_head or args.rate != 16000:

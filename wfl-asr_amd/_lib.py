@@ -62,6 +62,11 @@ SIGNATURES = {
     "wfl_host_load_wav": (_I, [C.c_char_p, _P, _L, _P, _P]),
     "wfl_host_load_wavs": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _I]),
     "wfl_host_load_wav_chunks": (_I, [C.c_char_p, _I, _L, _P, _L, _I, _P, _P, _P]),
+    "wfl_host_read_pcm16": (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _P, _I]),
+    "wfl_resample_workspace_bytes": (_L, [_I, _I]),
+    "wfl_resample_pcm16": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _L, _I, _P, _L, _P]),
+    "wfl_boundary_workspace_bytes": (_L, [_I, _I]),
+    "wfl_boundary_features": (_I, [_P, _L, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     "wfl_gemm_profile_enable": (_I, [_P, _I]),
     "wfl_gemm_profile_read": (_I, [_P, _I, _P, _P, _P, _P, _P, _I]),
 }

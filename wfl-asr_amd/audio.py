@@ -43,6 +43,58 @@ def wav_sample_rate(path: str):
     return None
 
 
+def wav_header(path: str):
+    """(format tag, channels, sample rate, bits per sample, data bytes) from the header alone (the first 4 KiB), or None when the `fmt `
+    and `data` chunk headers are not both found there / the file is not RIFF/WAVE.  (WAVE_FORMAT_EXTENSIBLE: the sub-format's tag.)"""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(4096)
+    except OSError:
+        return None
+    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        return None
+    pos, fmt = 12, None
+    while pos + 8 <= len(head):
+        cid = head[pos:pos + 4]
+        size = struct.unpack("<I", head[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            if pos + 8 + 16 > len(head):
+                return None
+            tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", head[pos + 8:pos + 24])
+            if tag == 0xFFFE and size >= 26 and pos + 8 + 26 <= len(head):
+                tag = struct.unpack("<H", head[pos + 32:pos + 34])[0]
+            fmt = (int(tag), int(ch), int(sr), int(bits))
+        elif cid == b"data":
+            return None if fmt is None else fmt + (int(size),)
+        pos += 8 + size + (size & 1)
+    return None
+
+
+def read_pcm16_into(paths, rows, cap: int, threads: int = 8):
+    """The 16-bit PCM samples of a batch of WAV files as they are (interleaved channels) into rows[i, :n_frames * channels] of an int16
+    [B, ld] buffer (normally pinned memory) -- the host side of the GPU ingest path (csrc/resample.hip).  -> (n_frames, channels,
+    sample_rates, status) int32 arrays; status 0 = done (include/wfl_asr.h: wfl_host_read_pcm16)."""
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    n = len(paths)
+    enc = [os.fsencode(p) for p in paths]
+    arr = (C.c_char_p * max(n, 1))(*enc)
+    nf = np.zeros(max(n, 1), np.int32)
+    ch = np.zeros(max(n, 1), np.int32)
+    srs = np.zeros(max(n, 1), np.int32)
+    st = np.zeros(max(n, 1), np.int32)
+    if hasattr(rows, "data_ptr"):
+        ptr, ld = rows.data_ptr(), rows.stride(0)
+    else:
+        ptr, ld = rows.ctypes.data, rows.strides[0] // 2
+    rc = lib.wfl_host_read_pcm16(arr, n, C.c_void_p(ptr), ld, int(cap), nf.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p),
+                                 srs.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), int(threads))
+    _lib.check(rc, "wfl_host_read_pcm16")
+    return nf[:n], ch[:n], srs[:n], st[:n]
+
+
 def read_wav(path: str):
     """-> (float64 mono samples, sample_rate)."""
     with open(path, "rb") as f:

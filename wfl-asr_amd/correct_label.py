@@ -10,8 +10,12 @@
 The reference computes the features with librosa 0.11 (`stft`, `feature.mfcc`, `feature.delta`); librosa is not available in this
 image and the reference holds no fixtures for this step, so the feature arithmetic is restated from librosa's documented
 definitions with numpy / scipy and its parity is UNPINNED (only its own properties are tested).  The snapping logic is exact
-Python and is pinned by a worked example.  Host-side: at 30 s per file the detector costs a few milliseconds; it is not on the
-GPU path.  Input audio must already be 16 kHz (librosa.load would resample with soxr, which is not restated).
+Python and is pinned by a worked example.  The two STFTs, the mel / dB / DCT chain and the flux run on the GPU when one is there
+(csrc/stft.hip through the C ABI: wfl_boundary_features; `device=None` picks it automatically, `device="cpu"` keeps the numpy
+restatement, which the GPU path is tested against); the delta filter, the peak picking and the snapping stay on the host (a few
+thousand values per file).  Input audio must already be 16 kHz (librosa.load would resample with soxr, which is not restated).
+Like the reference, an interrupted run leaves `<wav>_boundary.txt` behind and the next run reuses it (correct_label.py:89-104,
+153-161); `--save_plot` is not offered (matplotlib plotting is out of scope).
 """
 from __future__ import annotations
 
@@ -71,14 +75,65 @@ def _mfcc(y: np.ndarray, sr: int, n_mfcc: int, hop: int) -> np.ndarray:
     return dct(log_spec, axis=0, type=2, norm="ortho")[:n_mfcc]
 
 
-def detect_boundaries(y, sr, frame_length=512, hop_length=160, flux_threshold=0.1, delta_window=5):
-    """-> (boundary times [s], flux, mfcc-delta magnitude, frame times), as correct_label.py:15-38."""
+_GPU_TABLES = {}
+
+
+def gpu_available() -> bool:
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def boundary_features_gpu(y, device="cuda"):
+    """(flux before normalisation [F + 1 -> cut by the caller], mfcc [13, F]) of one 16 kHz clip from csrc/stft.hip: the same
+    quantities as `_stft_mag` / `_mfcc` below, float32 on the MFMA."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.device(device)
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float32))
+    L = int(y.shape[0])
+    if L <= 0:
+        raise ValueError("empty clip")
+    key = str(dev)
+    if key not in _GPU_TABLES:
+        from scipy.fft import dct
+        mel = _mel_slaney(16000, 2048, 128).astype(np.float32)                         # [128, 1025]
+        d = dct(np.eye(128), axis=0, type=2, norm="ortho")[:13].astype(np.float32)      # [13, 128]: row c = coefficient c's weights
+        _GPU_TABLES[key] = (torch.from_numpy(np.ascontiguousarray(mel)).to(dev), torch.from_numpy(np.ascontiguousarray(d)).to(dev))
+    mel_w, dctm = _GPU_TABLES[key]
+    F = 1 + L // 160
+    wav = torch.from_numpy(y).to(dev)
+    flux = torch.empty(F, dtype=torch.float32, device=dev)
+    mfcc = torch.empty(13, F, dtype=torch.float32, device=dev)
+    nb = int(lib.wfl_boundary_workspace_bytes(1, L))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    rc = lib.wfl_boundary_features(C.c_void_p(wav.data_ptr()), L, None, 1, L, C.c_void_p(mel_w.data_ptr()), C.c_void_p(dctm.data_ptr()),
+                                   C.c_void_p(flux.data_ptr()), C.c_void_p(mfcc.data_ptr()), C.c_void_p(ws.data_ptr()), nb,
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "wfl_boundary_features")
+    return flux.cpu().numpy(), mfcc.cpu().numpy()
+
+
+def detect_boundaries(y, sr, frame_length=512, hop_length=160, flux_threshold=0.1, delta_window=5, device=None):
+    """-> (boundary times [s], flux, mfcc-delta magnitude, frame times), as correct_label.py:15-38.  device: None = the GPU when there
+    is one (and the defaults n_fft 512 / hop 160 / 16 kHz are asked for), "cpu" = the numpy restatement."""
     from scipy.signal import find_peaks, savgol_filter
-    S = _stft_mag(y, frame_length, hop_length)
-    flux = np.sqrt(np.sum(np.diff(S, axis=1) ** 2, axis=0))
-    flux = np.pad(flux, (1,), mode="constant")
-    flux = flux / np.max(flux)
-    mfcc = _mfcc(y, sr, 13, hop_length)
+    use_gpu = device != "cpu" and frame_length == 512 and hop_length == 160 and sr == 16000 and (device is not None or gpu_available())
+    if use_gpu:
+        flux, mfcc = boundary_features_gpu(y, device or "cuda")
+        flux = flux / np.max(flux)
+    else:
+        S = _stft_mag(y, frame_length, hop_length)
+        flux = np.sqrt(np.sum(np.diff(S, axis=1) ** 2, axis=0))
+        flux = np.pad(flux, (1,), mode="constant")
+        flux = flux / np.max(flux)
+        mfcc = _mfcc(y, sr, 13, hop_length)
     delta = savgol_filter(mfcc, 9, deriv=1, axis=-1, polyorder=1, mode="interp")     # librosa.feature.delta defaults
     delta_mag = np.mean(np.abs(delta), axis=0)
     delta_mag = delta_mag / np.max(delta_mag)
@@ -143,7 +198,7 @@ def write_lab(wav_path, snapped_boundaries, out_path=None):
             f.write(f"{int(start * 1e7)} {int(end * 1e7)} {label}\n")
 
 
-def process_file(wav_path):
+def process_file(wav_path, device=None):
     """correct_label.py:153-177 without the plotting: detect (or reuse `<wav>_boundary.txt`), snap, rewrite the `.lab`."""
     y, sr = A.read_wav(wav_path)
     if sr != 16000:
@@ -154,7 +209,10 @@ def process_file(wav_path):
         with open(txt) as f:
             predicted = [float(line.strip()) for line in f if line.strip()]
     else:
-        predicted = detect_boundaries(y, sr)[0]
+        predicted = detect_boundaries(y, sr, device=device)[0]
+        with open(txt, "w") as f:                       # (correct_label.py:89-97, 160: what an interrupted run leaves behind)
+            for t in predicted:
+                f.write(f"{t:.6f}\n")
     snapped, _ = correct_lab_boundaries(wav_path, predicted)
     write_lab(wav_path, snapped)
     if os.path.exists(txt):

@@ -41,7 +41,7 @@ static __device__ __forceinline__ int k_swz(int row) {
   return (row >> 2) & 3;                      // CPR == 4
 }
 
-template <int HD, int QT, bool PREFETCH, bool BIAS>
+template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VPITCH = HD * 2 + 32;
@@ -312,6 +312,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const float l = __shfl(osum[qt][0], c);          // row sum of query c lives in lane (g = 0, c), register 0
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + c;
+    if (OUT8) {
+      if (q < T) {                                   // e4m3 with a fixed scale, saturating: four channels = four bytes per lane and tile
+        unsigned char* op8 = p.O8 + (row0 + q) * p.ldo8 + h * HD + g * 4;
+        const float sc = inv * p.o8_scale;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          float x[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fminf(fmaxf(o[qt][dt][e] * sc, -448.f), 448.f);
+          int w = 0;
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
+          *(int*)(op8 + dt * 16) = w;
+        }
+      }
+      continue;
+    }
     if (q < T) {
       bf16_t* op = p.O + (row0 + q) * p.ldo + h * HD + g * 4;
 #pragma unroll
@@ -325,11 +342,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 }
 
-template <int HD, int QT, bool PREFETCH, bool BIAS>
+template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   static_assert(!BIAS || PREFETCH, "the bias table slice is staged on the prefetch barrier");
   constexpr int lds = (PREFETCH ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32)) + (BIAS ? 2 * (KT + 4 * QT * 16) * 4 : 0);
-  auto k = attn_kernel<HD, QT, PREFETCH, BIAS>;
+  auto k = attn_kernel<HD, QT, PREFETCH, BIAS, OUT8>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
@@ -352,6 +369,10 @@ static int attn_variant() {
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldv % 8 || a.ldo % 4 || a.T <= 0 || !a.V) return -1;
   const int hd = a.d / a.heads;
+  if (a.O8) {
+    if (a.bias || hd != 64 || a.ldo8 % 4) return -4;
+    return launch_attn<64, 2, true, false, true>(a, s);
+  }
   if (a.bias) {
     if (!a.gate) return -1;
     switch (hd) {

@@ -54,6 +54,18 @@ struct GemmArgs {
   // fp8 weights (BASELINE configs[4]): W is [N][K] OCP e4m3 bytes, one fp32 scale per output channel; the tile is converted to
   // bf16 in registers (exact) in front of the bf16 MFMA, the scale multiplies the accumulator in the epilogue (gemm_stream.hip)
   const float* w8_scale;    //   [N] per-output-channel scale, non-null <=> W holds e4m3 bytes
+  // fp8 ACTIVATIONS as well (round 3; gemm_stream.hip, template A8): A holds OCP e4m3 bytes (lda in bytes, single tap), the value of
+  // element (m, k) is a8(m, k) * sa(m) with sa(m) = a8_scale[a8_lead + m] (one fp32 scale per A row, written by the kernel that
+  // quantised the row) or a8_static when a8_scale is null.  Needs w8_scale; the MFMA is v_mfma_f32_16x16x32_fp8_fp8, both scales
+  // multiply the accumulator in the epilogue.
+  int a8;
+  const float* a8_scale;
+  long a8_lead;
+  float a8_static;
+  // fp8 OUTPUT (with a8): instead of C, e4m3(out * c8_inv_scale) goes to c8 (ldc8 bytes per row, same row mapping as C)
+  unsigned char* c8;
+  long ldc8;
+  float c8_inv_scale;
   float alpha;              // out = res + alpha * act(v)
   const bf16_t* pos;        // [T][ldpos] added after the activation (positional table) or null
   long ldpos;
@@ -87,6 +99,11 @@ struct AttnArgs {
   const float* bias;      // optional additive score bias (WavLM gated rel-pos), see attention.hip
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
   const int* clip_T;      // [B] valid frames per clip (keys and queries >= clip_T[b] do not exist), or null: T for all
+  // fp8 context (BASELINE configs[4], round 3): instead of O, e4m3(context * o8_scale) goes to O8 (ldo8 bytes per row, same row mapping)
+  // -- the out-projection's fp8 operand, with the fixed scale 1 / o8_scale (GemmArgs::a8_static).  head_dim 64 only.
+  unsigned char* O8;
+  long ldo8;
+  float o8_scale;
 };
 
 // One BiLSTM layer's recurrence (lstm.hip)

@@ -72,10 +72,20 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 //   step is 8 KiB instead of 16 (one LDS-DMA piece per wave instead of two: 20 KiB per step instead of 28 -- the K loop is bound
 //   by exactly these bytes), fragments are read as 8 bytes and converted to bf16 in registers (v_cvt_pk_f32_fp8 +
 //   v_cvt_pk_bf16_f32, exact), the MFMA stays bf16 x bf16, the scale multiplies the accumulator in the epilogue.
-template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV, bool W8 = false>
+// A8: BOTH operands are e4m3 (GemmArgs::a8).  A row of 64 e4m3 values is as long as a row of 32 bf16 values, so the kernel stages,
+//   swizzles, counts and reads exactly as for bf16 -- the launcher presents the byte matrices as bf16 matrices of half the width -- and
+//   a 16-byte fragment holds the k's of TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and its high 8 bytes; frame and weight fragments
+//   split the same way, so the two instructions contract matching k's): a step moves the same 28 KiB for twice the FLOPs and holds 48
+//   MFMAs per wave between its two barriers instead of 24 -- the loop is bound by the matrix pipe, not by the operand DMA.  (Round 3's
+//   first form -- 32-byte rows, half-size stages -- kept the 24-MFMA step and its barrier overhead: 0.60 us per 32 k's against 0.79
+//   for W8 and ~0.45 now.)  The scales (per output channel, per frame row) multiply the accumulator in the epilogue.
+//   OUT8: the epilogue writes e4m3 (GemmArgs::c8) instead of bf16 -- fc1's GELU output, the next GEMM's fp8 operand.
+template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV, bool W8 = false, bool A8 = false, bool OUT8 = false>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   static_assert(!CONV || (MT == 6 && !RES && LNF == 0 && !STATS), "conv mode: 192-row tiles, plain epilogue");
   static_assert(!W8 || (!CONV && MT == 6), "fp8 weights: plain 192-row mode");
+  static_assert(!A8 || (!W8 && !CONV && MT == 6 && LNF == 0 && !STATS), "fp8 x fp8: the plain 192-row mode, no LayerNorm folding");
+  static_assert(!OUT8 || (A8 && !RES), "fp8 output: the fp8 x fp8 kernel, no residual");
   constexpr int BMV = MT * 32;                    // frame rows per tile
 #ifdef WFL_LAB_STB32
   constexpr int STB = 512 * SBK * 2;
@@ -269,15 +279,24 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   // ---- epilogue of tile (m0, n0): registers -> HBM
   auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
     const int nb = n0 + wn + 8 * g;                 // first channel of this lane's first run; second run at +32
-    f32x4 bj[4], sj[4], cj[W8 ? 4 : 1];
+    f32x4 bj[4], sj[4], cj[(W8 || A8) ? 4 : 1];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         bj[2 * h + q] = p.bias ? *(const f32x4*)(p.bias + nb + 32 * h + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (LNF) sj[2 * h + q] = *(const f32x4*)(p.ln_s + nb + 32 * h + 4 * q);
-        if (W8) cj[2 * h + q] = *(const f32x4*)(p.w8_scale + nb + 32 * h + 4 * q);
+        if (W8 || A8) cj[2 * h + q] = *(const f32x4*)(p.w8_scale + nb + 32 * h + 4 * q);
       }
+    float sa[A8 ? MT : 1];                          // A8: the frame rows' scales
+    if (A8) {
+#pragma unroll
+      for (int u = 0; u < MT; ++u) {
+        int m = m0 + wm + 16 * u + c;
+        m = m < p.M ? m : p.M - 1;
+        sa[u] = p.a8_scale ? p.a8_scale[p.a8_lead + m] : p.a8_static;
+      }
+    }
     const float invP = 1.0f / (float)p.P;
     int orow[MT];                                   // output row index, or -1 for rows that are not stored
 #pragma unroll
@@ -360,7 +379,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[u][2 * h + q][e];
-            if (W8) v *= cj[2 * h + q][e];
+            if (W8 || A8) v *= cj[2 * h + q][e];
+            if (A8) v *= sa[u];
             if (LNF) v = (v - mu[u] * sj[2 * h + q][e]) * rs[u];
             v = apply_act<ACT>(v + bj[2 * h + q][e]);
             if (RES) v = (bf2f(rr[u % RING][h][4 * q + e]) + lo_scale * bf2f(rl[u % RING][h][4 * q + e])) + p.alpha * v;
@@ -370,6 +390,17 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(x[e]);
         const bool keep = orow[u] >= 0 && nb + 32 * h < p.n_valid;
+        if (OUT8) {                                  // e4m3 (saturating at +-448) instead of bf16: 8 bytes per run of 8 channels
+          int w0 = 0, w1 = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fminf(fmaxf(x[e] * p.c8_inv_scale, -448.f), 448.f);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], w1, true);
+          char* d8 = (char*)(p.c8 + (long)orow[u] * p.ldc8 + nb + 32 * h);
+          d8 = keep ? d8 : trash;
+          *(uint2*)d8 = make_uint2((unsigned)w0, (unsigned)w1);
+          continue;
+        }
         char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
         dst = keep ? dst : trash;
         *(bf16x8*)dst = o;
@@ -472,7 +503,14 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
+      for (int v = 0; v < 4; ++v) {
+        if (A8) {                                    // a 16-byte fragment = the k's of two fp8 MFMAs (low half, high half)
+          typedef __attribute__((ext_vector_type(2))) long i64x2;
+          const i64x2 a = __builtin_bit_cast(i64x2, fw[v]), b = __builtin_bit_cast(i64x2, fx[u]);
+          acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[0], b[0], acc[u][v], 0, 0, 0);
+          acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[1], b[1], acc[u][v], 0, 0, 0);
+        } else acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[v], fx[u], acc[u][v], 0, 0, 0);
+      }
       if (NDC >= 1 && u == 1) { __builtin_amdgcn_sched_barrier(0); issue_deferred(0, ndc_c); __builtin_amdgcn_sched_barrier(0); }
       if (NDC >= 2 && u == 3) { __builtin_amdgcn_sched_barrier(0); issue_deferred(1, ndc_c); __builtin_amdgcn_sched_barrier(0); }
       if (LNF == 1) {
@@ -585,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #undef SSB
 }
 
-template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV = false, bool W8 = false>
+template <int ACT, int MT, bool RES, int LNF, bool STATS, bool CONV = false, bool W8 = false, bool A8 = false, bool OUT8 = false>
 static int launch_stream(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
 #ifdef WFL_LAB_STB32
@@ -594,12 +632,12 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = (CONV ? SNST * 256 * SBK * 2 + 2 * 224 * SBK * 2 : SNST * (BMV * SBK * 2 + 256 * SBK * (W8 ? 1 : 2))) + 8 * (MT * 16) * 2 * 4 + 64;
 #endif
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / 256);
-  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV, W8>;
+  auto k = gemm_stream_kernel<ACT, MT, RES, LNF, STATS, CONV, W8, A8, OUT8>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
-  g_wfl_gemm_kernel_id = CONV ? 6 : (W8 ? 7 : (MT == 6 ? 1 : 5));
+  g_wfl_gemm_kernel_id = CONV ? 6 : (W8 ? 7 : (MT == 6 ? 1 : 5));     // (7: both fp8 forms)
   hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -641,7 +679,10 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
 #endif
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
   if (a.c_lo && !a.res) return false;
-  if (a.w8_scale && (a.cin < a.K || a.K % 64)) return false;                 // only the residual epilogue here keeps a low half (gemm256 / gemm do it for any)
+  if (a.w8_scale && (a.cin < a.K || a.K % 64)) return false;
+  if (a.a8 && (!a.w8_scale || a.ln_s || a.stats_out || a.stats_in || a.K % 128 || a.lda % 16 || a.K / 64 < 8 || (a.c8 && (a.res || a.ldc8 % 8))))
+    return false;
+  if (a.c8 && !a.a8) return false;                 // only the residual epilogue here keeps a low half (gemm256 / gemm do it for any)
   if (a.N % 256 || a.K % SBK || a.cin % SBK || a.K / SBK < 8 || a.n_valid % 8) return false;
   // (no lower bound on M: a LayerNorm folded through the producer's statistics must not depend on the batch size -- a clip
   // labelled alone has to equal the same clip inside a batch bit for bit)
@@ -665,6 +706,15 @@ int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs g = a;
   g.trash = trash[dev];
+  if (g.a8) {
+    // fp8 x fp8 (BASELINE configs[4]): q|k|v (plain), out_proj / fc2 (residual hi + lo), fc1 (GELU, e4m3 out).  The kernel sees both
+    // byte matrices as bf16 matrices of half the width (the note at the kernel): K, cin and lda in 2-byte units.
+    g.K /= 2; g.cin = g.K; g.lda /= 2;
+    if (g.c8) return g.act == WFL_ACT_GELU ? launch_stream<WFL_ACT_GELU, 6, false, 0, false, false, false, true, true>(g, s) : -1;
+    if (g.res) return g.act == WFL_ACT_NONE ? launch_stream<WFL_ACT_NONE, 6, true, 0, false, false, false, true>(g, s) : -1;
+    if (g.act == WFL_ACT_NONE) return launch_stream<WFL_ACT_NONE, 6, false, 0, false, false, false, true>(g, s);
+    return -1;
+  }
   if (g.w8_scale) {
     // fp8-weight launches: the Whisper encoder's LayerNorm-folded projections (statistics from the producer) and its residual
     // GEMMs (statistics emitted), i.e. everything between the stem and the final LayerNorm

@@ -355,6 +355,32 @@ void resample_f64(const std::vector<double>& x, int orig_freq, int new_freq, std
   if (out.size() > target) out.resize(target);
 }
 
+// One file's 16-bit PCM samples as they are (interleaved), for the GPU ingest path (resample.hip).  status: 0 ok; 1 not a 16-bit PCM
+// WAV; 2 more than 2 channels; 3 more than cap_samples int16 values (n_frames = the frame count); 4 cannot open
+int read_pcm16_one(const char* path, int16_t* out, long cap_samples, int32_t* n_frames, int32_t* channels, int32_t* sr_out) {
+  *n_frames = 0; *channels = 0; *sr_out = 0;
+  FILE* f = fopen(path, "rb");
+  if (!f) return 4;
+  std::vector<unsigned char> d;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (sz > 0) { d.resize((size_t)sz); if (fread(d.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return 4; } }
+  fclose(f);
+  WavInfo w;
+  if (!parse_wav(d, w)) return 1;
+  *sr_out = w.sr;
+  if (w.tag != 1 || w.bits != 16 || w.ch < 1) return 1;
+  if (w.ch > 2) return 2;
+  const size_t total = w.pcm_bytes / 2;
+  const size_t frames = total / (size_t)w.ch;
+  *channels = w.ch;
+  *n_frames = (int32_t)std::min<size_t>(frames, 0x7fffffff);
+  if ((long)(frames * (size_t)w.ch) > cap_samples) return 3;
+  memcpy(out, w.pcm, frames * (size_t)w.ch * 2);
+  return 0;
+}
+
 // status: 0 ok; 1 not a WAV / unsupported encoding; 2 more than 2 channels; 3 longer than cap; 4 cannot open
 int load_one(const char* path, float* out, long cap, int32_t* n_out, int32_t* sr_out) {
   *n_out = 0;
@@ -388,6 +414,27 @@ int32_t wfl_host_load_wavs(const char* const* paths, int32_t n, float* out, int6
       const int i = next.fetch_add(1);
       if (i >= n) break;
       status[i] = load_one(paths[i], out + (size_t)i * (size_t)ld, (long)cap, n_samples + i, sample_rates + i);
+    }
+  };
+  if (threads == 1) { work(); return 0; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+  for (auto& t : pool) t.join();
+  return 0;
+}
+
+// rows: out + i * ld int16 values each (room for cap_samples interleaved samples); dealt to `threads` workers
+int32_t wfl_host_read_pcm16(const char* const* paths, int32_t n, int16_t* out, int64_t ld, int64_t cap_samples, int32_t* n_frames,
+                            int32_t* channels, int32_t* sample_rates, int32_t* status, int32_t threads) {
+  if (n < 0 || (n && (!paths || !out || !n_frames || !channels || !sample_rates || !status)) || cap_samples > ld) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n > 0 ? n : 1;
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      status[i] = read_pcm16_one(paths[i], out + (size_t)i * (size_t)ld, (long)cap_samples, n_frames + i, channels + i, sample_rates + i);
     }
   };
   if (threads == 1) { work(); return 0; }

@@ -411,18 +411,20 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
   // workgroups are resident -- one per CU, ~133 KiB of LDS each -- and launches are plain, so nothing checks that.  Two rules keep a
   // team from ever waiting on a CU that another waiting team holds:
   //   (1) a launch has at most 128 workgroups (whole teams), half the chip;
-  //   (2) recurrence launches of one device run ONE AT A TIME, whatever the number of batches in flight: each launch waits for the
-  //       event recorded behind the previous one (any stream, any model) before it starts.  What other streams run meanwhile are
-  //       GEMM / attention / element-wise kernels, which finish without waiting for anybody: the recurrence's workgroups take their CUs
-  //       as those kernels' workgroups retire (at worst one persistent GEMM launch later).
+  //   (2) at most TWO recurrence launches of one device are in flight, whatever the number of batches in flight: launch n waits for the
+  //       event recorded behind launch n - 2 (any stream, any model) before it starts.  Two launches are at most 256 workgroups = the
+  //       chip's CUs, so both become fully resident as soon as the other streams' GEMM / attention / element-wise workgroups -- which
+  //       finish without waiting for anybody -- have retired (at worst one persistent GEMM launch later); a third could leave all three
+  //       partially resident, each holding CUs the others wait for.
   // Round 2 relied on (1) alone ("two launches always fit the chip"), which three or more batches in flight -- the default for this
   // head -- broke: partially resident teams of several launches held each other's CUs until other streams' kernels drained
   // (the cfg3 sweep that fell from 15.2 k to 5.0 k audio-s/s at four in flight).  Overlap is not lost: a batch's
-  // recurrence still runs under the other batches' GEMMs, only never under another recurrence.
+  // recurrence still runs under the other batches' GEMMs and under ONE other recurrence.
   // (Not while the stream is being captured into a graph: an event of another stream would pull that stream into the capture.  Graph
   //  replay keeps at most two slots in flight, for which (1) is enough.)
   static std::mutex chain_mu;
-  static hipEvent_t chain_ev[32] = {nullptr};
+  static hipEvent_t chain_ev[32][2] = {{nullptr, nullptr}};
+  static unsigned chain_n[32] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev &= 31;
@@ -432,9 +434,10 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
   std::unique_lock<std::mutex> chain_lock(chain_mu, std::defer_lock);
   if (chained) {
     chain_lock.lock();                     // (wait -> launches -> record must not interleave with another host thread's)
-    if (!chain_ev[dev]) {
-      if (hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) return -2;
-    } else if (hipStreamWaitEvent(s, chain_ev[dev], 0) != hipSuccess) return -3;
+    hipEvent_t& ev = chain_ev[dev][chain_n[dev] & 1];
+    if (!ev) {
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -2;
+    } else if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) return -3;
   }
   const int per = 128 / (2 * a.G) > 0 ? 128 / (2 * a.G) : 1;
   for (int g0 = 0; g0 < groups; g0 += per) {
@@ -455,6 +458,9 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
     }
     if (r) return r;
   }
-  if (chained && hipEventRecord(chain_ev[dev], s) != hipSuccess) return -3;
+  if (chained) {
+    if (hipEventRecord(chain_ev[dev][chain_n[dev] & 1], s) != hipSuccess) return -3;
+    ++chain_n[dev];
+  }
   return 0;
 }

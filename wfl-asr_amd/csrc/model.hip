@@ -82,6 +82,8 @@ int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, con
                              int n_div = 0, const int* clip_T = nullptr);
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
+int wfl_launch_rows_fp8(const bf16_t* x, long ldx, const bf16_t* x_lo, const float* g, const float* b, float eps, long lead, int B, int P,
+                        int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s);          // norm.hip
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
 struct ZeroMulti {
   int n;
@@ -1063,6 +1065,7 @@ struct Plan {
   // byte offsets
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
   long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, QKp, ATTp, clipT, total;
+  long X8, FF8, rs8;            // fp8 activations (fp8_weights models): e4m3 rows [R][d], [R][ffw], fp32 row scales [R]
   int da;                       // Conformer attention width (wfl_model::conf_da); QKp / ATTp exist when it differs from d
 };
 
@@ -1133,6 +1136,11 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   if (p.da != p.d) {
     p.QKp = take(p.R * 3 * p.da * 2);
     p.ATTp = take(p.R * p.da * 2);
+  }
+  if (a.fp8_weights && T_frames <= 0) {
+    p.X8 = take(p.R * (long)p.d);
+    p.FF8 = take(p.R * (long)p.ffw);
+    p.rs8 = take(p.R * 4L);
   }
   p.stats = take(p.R * 4L * 2 * 4);                     // per row, per 256-column tile (<= 4): (sum, sum of squares)
   p.enc2 = take(p.R * p.d * 2);
@@ -1206,6 +1214,13 @@ struct Runner {
   bool next_lo_out = false;     // the next gemm() produces a residual-stream tensor: keep its low half
   bool next_acc_f32 = false;    // the next gemm() (fp32 output) adds to what is there
   double next_flops = -1.0;     // >= 0: algorithmic FLOPs to book for the next gemm() instead of 2 M N K
+  // fp8 activations (GemmArgs::a8): the next gemm()'s A operand is e4m3 bytes with these scales / its output goes out as e4m3
+  bool next_a8 = false;
+  const float* next_a8_scale = nullptr;
+  float next_a8_static = 1.f;
+  unsigned char* next_c8 = nullptr;
+  long next_ldc8 = 0;
+  float next_c8_inv = 1.f;
   // LayerNorm statistics left behind by the last residual GEMM (gemm_stream.hip, STATS): valid for the rows of `stats_for`
   const void* stats_for = nullptr;
   int stats_nsl = 0;
@@ -1233,6 +1248,11 @@ struct Runner {
     g.pos = pos; g.ldpos = ldpos;
     g.act = act; g.glu = glu ? 1 : 0; g.out_f32 = out_f32 ? 1 : 0;
     g.acc_f32 = (out_f32 && next_acc_f32) ? 1 : 0;
+    if (next_a8) {
+      g.a8 = 1; g.a8_scale = next_a8_scale; g.a8_lead = p.lead; g.a8_static = next_a8_static;
+      g.c8 = next_c8; g.ldc8 = next_ldc8; g.c8_inv_scale = next_c8_inv;
+      next_a8 = false; next_a8_scale = nullptr; next_c8 = nullptr;
+    }
     if (!out_f32 && !glu && (res || next_lo_out)) g.c_lo = lo_of(C);
     if (res) g.res_lo = lo_in(res);
     { const int ci = out_f32 ? -1 : lo_idx(C); if (ci >= 0) lo_ok[ci] = g.c_lo != nullptr; }
@@ -1335,10 +1355,12 @@ struct Runner {
   }
 
   // padded: the Conformer attention at width p.da != p.d (head size rounded up to a built one): q | k | v rows in QKp, context in ATTp
-  void attn(int heads, const float* bias = nullptr, const float* gate = nullptr, bool padded = false) {
+  void attn(int heads, const float* bias = nullptr, const float* gate = nullptr, bool padded = false, unsigned char* o8 = nullptr,
+            long ldo8 = 0, float o8_scale = 1.f) {
     if (rc) return;
     AttnArgs a{};
     a.bias = bias; a.gate = gate;
+    a.O8 = o8; a.ldo8 = ldo8; a.o8_scale = o8_scale;
     const int w = padded ? p.da : p.d;
     bf16_t* qk = buf(padded ? p.QKp : p.QK);
     a.QK = qk; a.ldqk = 3 * w; a.lead = p.lead; a.V = qk + 2 * w; a.ldv = 3 * w; a.O = buf(padded ? p.ATTp : p.ATT); a.ldo = w;
@@ -1462,7 +1484,48 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     R.next_lo_out = true;                            // the residual stream starts here
     R.gemm(c1 + (long)(p.lead2 - 1) * d, 2 * d, m->conv2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0,
            1.f, 0, 0, false, false, m->pos, d);
-    for (int i = 0; i < a.enc_layers; ++i) {
+    // fp8 x fp8 (BASELINE configs[4]; WFL_FP8_ACT=0: fp8 weights with bf16 activations, round 2's form): every GEMM operand of a layer
+    // is e4m3 -- LayerNorm outputs and the attention context with one scale per row (norm.hip), fc1's GELU output straight from its
+    // epilogue with a fixed scale -- and the four GEMMs run on v_mfma_f32_16x16x32_fp8_fp8 (gemm_stream.hip, A8)
+    static int fp8_act = -1;
+    if (fp8_act < 0) { const char* e = getenv("WFL_FP8_ACT"); fp8_act = e ? atoi(e) : 1; }
+    const bool act8 = a.fp8_weights && fp8_act && p.X8 > 0 && p.ffw == a.enc_ffn;
+    for (int i = 0; act8 && i < a.enc_layers; ++i) {
+      const EncLayer& L_ = m->enc[i];
+      unsigned char* X8 = (unsigned char*)(R.ws + p.X8);
+      unsigned char* FF8 = (unsigned char*)(R.ws + p.FF8);
+      float* rs8 = (float*)(R.ws + p.rs8);
+      const float ff_scale = 8.0f;                     // fc1's GELU output is stored as e4m3(8 x): |x| <= 56, normal numbers down to 2^-9
+      auto rows8 = [&](const bf16_t* x, const bf16_t* x_lo, const LNp* w) {
+        if (R.rc) return;
+        R.prof_begin();
+        const int r = wfl_launch_rows_fp8(x, d, x_lo, w ? w->g : nullptr, w ? w->b : nullptr, 1e-5f, p.lead, B, p.P, p.T, d, X8, d, rs8, R.s);
+        R.prof_end(2043, 0.0);
+        if (r) R.rc = fail(r, "rows_fp8 launch failed");
+      };
+      rows8(X, R.lo_in(X), &L_.ln1);
+      R.next_a8 = true; R.next_a8_scale = rs8;
+      R.gemm((const bf16_t*)(X8 + (long)p.lead * d), d, L_.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P, WFL_ACT_NONE);
+      // the attention context leaves the attention kernel as e4m3 with a fixed scale (head_dim 64; other head sizes: bf16, then
+      // quantised per row): a context row is a convex combination of value rows, |x| <= max |v|
+      const float att_scale = 8.0f;
+      if (d / a.enc_heads == 64) {
+        R.attn(a.enc_heads, nullptr, nullptr, false, X8, d, att_scale);
+        R.next_a8 = true; R.next_a8_scale = nullptr; R.next_a8_static = 1.0f / att_scale;
+      } else {
+        R.attn(a.enc_heads);
+        rows8(ATT, nullptr, nullptr);
+        R.next_a8 = true; R.next_a8_scale = rs8;
+      }
+      R.gemm((const bf16_t*)(X8 + (long)p.lead * d), d, L_.out, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
+      rows8(X, R.lo_in(X), &L_.ln2);
+      R.next_a8 = true; R.next_a8_scale = rs8;
+      R.next_c8 = FF8 + (long)p.lead * p.ffw * 0; R.next_ldc8 = p.ffw; R.next_c8_inv = ff_scale;
+      R.gemm((const bf16_t*)(X8 + (long)p.lead * d), d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
+      R.next_a8 = true; R.next_a8_scale = nullptr; R.next_a8_static = 1.0f / ff_scale;
+      R.gemm((const bf16_t*)(FF8 + (long)p.lead * p.ffw), p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
+    }
+    for (int i = 0; !act8 && i < a.enc_layers; ++i) {
       const EncLayer& L_ = m->enc[i];
       R.ln_gemm(X, Y, L_.ln1, L_.qkv, L_.qkv_ln, (int)Mrows, QK, 3 * d, WFL_ACT_NONE);
       R.attn(a.enc_heads);

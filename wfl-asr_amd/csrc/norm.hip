@@ -110,6 +110,120 @@ int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const f
   return wfl_launch_layernorm_act(x, ldx, y, ldy, g, b, eps, lead, B, P, T, C, 0, s, nullptr, nullptr, 0, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------- e4m3 rows (BASELINE configs[4], round 3)
+// The fp8 x fp8 GEMMs (gemm_stream.hip, A8) take their frame operand as OCP e4m3 bytes with one fp32 scale per row (row maximum -> 448):
+//   layernorm_fp8_kernel   LayerNorm of a residual-stream row (hi + lo) written as e4m3 + scale    (HF modeling_whisper.py:384, 399)
+//   quant_rows_fp8_kernel  bf16 rows (the attention context) -> e4m3 + scale
+// One wave per row, 8 channels per lane per step; scale[row index of the buffer].
+static __device__ __forceinline__ void store_row_fp8(float (*v)[8], int nch, int C, int lane, unsigned char* yp, float* scale_out) {
+  float mx = 0.f;
+  for (int i = 0; i < nch; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[i][e]));
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+  const float scale = mx > 0.f ? mx * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / scale;
+  for (int i = 0; i < nch; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < C) {
+      float q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = fminf(fmaxf(v[i][e] * inv, -448.f), 448.f);
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+      *(uint2*)(yp + c0) = make_uint2((unsigned)w0, (unsigned)w1);
+    }
+  }
+  if (lane == 0) *scale_out = scale;
+}
+
+template <int NCH, bool NORM>
+__global__ __launch_bounds__(256) void rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ x_lo,
+                                                       const float* __restrict__ gam, const float* __restrict__ bet, float eps, long lead,
+                                                       int B, int P, int T, int C, unsigned char* __restrict__ y8, long ldy8,
+                                                       float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long)B * T) return;
+  const int b = (int)(r / T), t = (int)(r - (long)b * T);
+  const long row = lead + (long)b * P + t;
+  const bf16_t* xp = x + row * ldx;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < C) {
+      const bf16x8 a = *(const bf16x8*)(xp + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = bf2f(a[e]);
+      if (x_lo) {
+        const bf16x8 al = *(const bf16x8*)(x_lo + row * ldx + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] += bf2f(al[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  if (NORM) {                                   // (the same arithmetic as layernorm_kernel: mean, then centred variance)
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (i * 64 + lane) * 8;
+      if (c0 < C) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+      }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+    const float rstd = rsqrtf(fmaxf(sq, 0.f) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c0 = (i * 64 + lane) * 8;
+      if (c0 < C) {
+        const f32x4 g0 = *(const f32x4*)(gam + c0), g1 = *(const f32x4*)(gam + c0 + 4);
+        const f32x4 b0 = *(const f32x4*)(bet + c0), b1 = *(const f32x4*)(bet + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[i][e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+          v[i][4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+        }
+      }
+    }
+  }
+  store_row_fp8(v, NCH, C, lane, y8 + row * ldy8, scale + row);
+}
+
+// g == null: plain quantisation of the bf16 rows (x_lo is still added when given); else LayerNorm(g, b, eps) first
+int wfl_launch_rows_fp8(const bf16_t* x, long ldx, const bf16_t* x_lo, const float* g, const float* b, float eps, long lead, int B, int P,
+                        int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s) {
+  if (C % 8 || ldx % 8 || ldy8 % 8 || C > 2048 || !y8 || !scale) return -1;
+  const long rows = (long)B * T;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define WFL_ROWS8(NCH)                                                                                                                  \
+  do {                                                                                                                                  \
+    if (g) hipLaunchKernelGGL((rows_fp8_kernel<NCH, true>), grid, dim3(256), 0, s, x, ldx, x_lo, g, b, eps, lead, B, P, T, C, y8, ldy8, scale);   \
+    else hipLaunchKernelGGL((rows_fp8_kernel<NCH, false>), grid, dim3(256), 0, s, x, ldx, x_lo, g, b, eps, lead, B, P, T, C, y8, ldy8, scale);    \
+  } while (0)
+  if (C <= 512) WFL_ROWS8(1); else if (C <= 1024) WFL_ROWS8(2); else WFL_ROWS8(4);
+#undef WFL_ROWS8
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // Zero every row that is not a valid frame: [0, lead), each clip's [T, P), and `tail_rows` rows behind the last
 // clip.  ld_bytes = bytes per row (multiple of 16).
 __global__ __launch_bounds__(256) void zero_halo_kernel(char* buf, long ld_bytes, long lead, int B, int P, int T,

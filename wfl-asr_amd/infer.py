@@ -14,6 +14,7 @@ batched loop over 30 s work items.
 """
 from __future__ import annotations
 
+import math
 import os
 import sys
 
@@ -115,7 +116,7 @@ class Labeler:
         self._run_batches((len(items) + Bs - 1) // Bs, fill, take, lang_id, threshold)
         return out
 
-    def _run_batches(self, n_batches, fill, take, lang_id, threshold):
+    def _run_batches(self, n_batches, fill, take, lang_id, threshold, pinned_in=None, upload=None):
         """The pipelined hot loop.  NS = `n_inflight` batches in flight on the GPU (two, or three for a BiLSTM behind a small
         encoder -- tagger.batches_in_flight; stream and workspace slot k % NS, own pinned output buffer), one more being filled:
         `fill(k, pinned_rows) -> (lens, rows used)` runs on a worker thread one batch ahead of the launches (the native loader
@@ -129,9 +130,14 @@ class Labeler:
         T = self.model.num_frames(L)
         NS = self.n_inflight
         NI = NS + 1
-        if self._pinned is None or len(self._pinned) != NI or self._pinned[0].shape[0] != Bs:
+        # pinned_in / upload: another staging format (the GPU ingest path: int16 PCM rows, resampled on the device -- _label_resampled);
+        # default: float32 waveform rows copied as they are
+        if pinned_in is None and (self._pinned is None or len(self._pinned) != NI or self._pinned[0].shape[0] != Bs):
             self._pinned = [torch.zeros(Bs, L, dtype=torch.float32).pin_memory() for _ in range(NI)]
+        if getattr(self, "_pinned_out", None) is None or len(self._pinned_out) != NS or self._pinned_out[0].numel() != Bs * T * 4 + 1:
             self._pinned_out = [torch.empty(Bs * T * 4 + 1, dtype=torch.int32).pin_memory() for _ in range(NS)]
+        pin = pinned_in if pinned_in is not None else self._pinned
+        assert len(pin) == NI
         self._ensure_streams()
         use_pipe = not self.use_graph
         pending = [None] * NS
@@ -153,7 +159,7 @@ class Labeler:
             ib = k % NI
             if copied[ib] is not None:
                 copied[ib].synchronize()                   # (NS + 1 batches back: long done)
-            return fill(k, self._pinned[ib])
+            return fill(k, pin[ib])
 
         if n_batches <= 0:
             return
@@ -165,10 +171,13 @@ class Labeler:
                     fut = pool.submit(fill_job, k + 1)
                 slot = k % NS if use_pipe else 0
                 finish(slot)                               # the output buffer and workspace of this slot are free again
-                host = self._pinned[k % NI]
+                host = pin[k % NI]
                 stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
                 with torch.cuda.stream(stream):
-                    dev_wav = host.to(self.device, non_blocking=True)
+                    if upload is None:
+                        dev_wav = host.to(self.device, non_blocking=True)
+                    else:
+                        dev_wav, lens = upload(host, lens, slot, stream)
                     ev_in = torch.cuda.Event()
                     ev_in.record(stream)
                     copied[k % NI] = ev_in
@@ -212,8 +221,25 @@ class Labeler:
             jobs = [idxs[s:s + Bs] for n, idxs in by_len.items() for s in range(0, len(idxs), Bs)]
         self._ensure_streams()
         NS = self.n_inflight
+        NI = NS + 1
+        if not jobs:
+            return out
+        # pinned staging sized once for the largest batch (round 2 grew the buffers lazily inside the loop): NS + 1 input buffers, so that
+        # a worker thread fills batch k + 1 while the main thread launches batch k (the same pipeline as _run_batches), NS output buffers
+        geom = []
+        for sel in jobs:
+            n = max(len(items[i]) for i in sel)
+            geom.append((n, self.model.num_frames(n), all(len(items[i]) == n for i in sel)))
+        need_in = max(len(sel) * g[0] for sel, g in zip(jobs, geom))
+        need_out = max(len(sel) * g[1] * 4 + 1 for sel, g in zip(jobs, geom))
+        cache = getattr(self, "_pinned_ragged", None)
+        if cache is None or len(cache[0]) != NI or cache[0][0].numel() < need_in or len(cache[1]) != NS or cache[1][0].numel() < need_out:
+            cache = ([torch.empty(need_in, dtype=torch.float32).pin_memory() for _ in range(NI)],
+                     [torch.empty(need_out, dtype=torch.int32).pin_memory() for _ in range(NS)])
+            self._pinned_ragged = cache
+        pin_in, pin_out = cache
         pending = [None] * NS
-        pin_in, pin_out = [None] * NS, [None] * NS
+        copied = [None] * NI                               # event behind the last H2D copy out of input buffer i
 
         def finish(slot):
             job = pending[slot]
@@ -230,32 +256,45 @@ class Labeler:
                 out[i] = (ids[j, :frames[i]].copy(), offs[j, :frames[i]].copy())
             pending[slot] = None
 
-        for k, sel in enumerate(jobs):
-            slot = k % NS
-            finish(slot)
-            n = max(len(items[i]) for i in sel)
-            same = all(len(items[i]) == n for i in sel)
-            T = self.model.num_frames(n)
-            need_in, need_out = len(sel) * n, len(sel) * T * 4 + 1
-            if pin_in[slot] is None or pin_in[slot].numel() < need_in:
-                pin_in[slot] = torch.empty(need_in, dtype=torch.float32).pin_memory()
-            if pin_out[slot] is None or pin_out[slot].numel() < need_out:
-                pin_out[slot] = torch.empty(need_out, dtype=torch.int32).pin_memory()
-            host = pin_in[slot][:need_in].view(len(sel), n)
+        def fill_job(k):
+            sel = jobs[k]
+            n, T, same = geom[k]
+            ib = k % NI
+            if copied[ib] is not None:
+                copied[ib].synchronize()                   # (NS + 1 batches back: long done)
+            host = pin_in[ib][:len(sel) * n].view(len(sel), n)
             rows = host.numpy()
             for j, i in enumerate(sel):
-                rows[j, :len(items[i])] = items[i]
-            lens = None if same else np.array([len(items[i]) for i in sel], np.int32)
-            with torch.cuda.stream(self._streams[slot]):
-                wav = host.to(self.device, non_blocking=True)
-                res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold, lens=lens,
-                                       average_languages=lang_id is None, slot=slot)
-                pin_out[slot][:need_out].copy_(res.packed, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._streams[slot])
-            pending[slot] = (sel, T, ev)
-        for k in range(max(0, len(jobs) - NS), len(jobs)):
-            finish(k % NS)
+                m = len(items[i])
+                rows[j, :m] = items[i]
+                if m < n:
+                    rows[j, m:] = 0.0                      # (behind a shorter clip: never read -- `lens` -- but keep the buffer defined)
+            return host, (None if same else np.array([len(items[i]) for i in sel], np.int32))
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(fill_job, 0)
+            for k, sel in enumerate(jobs):
+                host, lens = fut.result()
+                if k + 1 < len(jobs):
+                    fut = pool.submit(fill_job, k + 1)
+                slot = k % NS
+                finish(slot)
+                n, T, same = geom[k]
+                need_o = len(sel) * T * 4 + 1
+                with torch.cuda.stream(self._streams[slot]):
+                    wav = host.to(self.device, non_blocking=True)
+                    ev_in = torch.cuda.Event()
+                    ev_in.record(self._streams[slot])
+                    copied[k % NI] = ev_in
+                    res = self.model.label(wav, None if lang_id is None else [lang_id] * len(sel), threshold=threshold, lens=lens,
+                                           average_languages=lang_id is None, slot=slot)
+                    pin_out[slot][:need_o].copy_(res.packed, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._streams[slot])
+                pending[slot] = (sel, T, ev)
+            for k in range(max(0, len(jobs) - NS), len(jobs)):
+                finish(k % NS)
         return out
 
     def _lang_name(self, lang_id):
@@ -346,6 +385,87 @@ class Labeler:
             post.shutdown(wait=True)
         return done
 
+    def _label_resampled(self, audio_paths, src_sr, lang_id, threshold, lang_name):
+        """Files of ONE sample rate other than the model's, 16-bit PCM, at most 30 s: their samples go to the GPU as they are (the native
+        reader copies the file's PCM bytes into pinned int16 rows) and csrc/resample.hip decodes, resamples (float64 sinc, torchaudio's
+        published algorithm: infer.py:217-220) and peak-normalises (infer.py:234-235) them into the batch the forward reads -- the host's
+        cores no longer bound a 44.1 kHz folder (48 k audio-s/s with the host resampler).  Same pipeline, post-
+        processing and result as _label_fast."""
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
+
+        from . import _lib
+        lib = _lib.load()
+        Bs, L = self.batch_size, CHUNK_SAMPLES
+        NI = self.n_inflight + 1
+        cap_in = 2 * (int(math.ceil(L * src_sr / self.sr)) + 2)          # interleaved int16 values of a 30 s two-channel file
+        key = (src_sr, Bs)
+        cache = getattr(self, "_pinned_pcm", None)
+        if cache is None or cache[0] != key or len(cache[1]) != NI:
+            cache = (key, [torch.zeros(Bs, cap_in, dtype=torch.int16).pin_memory() for _ in range(NI)])
+            self._pinned_pcm = cache
+        pin = cache[1]
+        ws_bytes = int(lib.wfl_resample_workspace_bytes(Bs, L))
+        dev_out, dev_ws = {}, {}
+        meta, done, futures = {}, {}, []
+        self._names_for(lang_name)
+        post = ThreadPoolExecutor(max_workers=1)
+        threads = max(1, min(16, (os.cpu_count() or 1)))
+
+        def fill(k, host):
+            sel = list(range(k * Bs, min((k + 1) * Bs, len(audio_paths))))
+            nf, ch, srs, st = A.read_pcm16_into([audio_paths[i] for i in sel], host, cap_in, threads)
+            frames = np.zeros(Bs, np.int32)
+            chans = np.ones(Bs, np.int32)
+            ok = []
+            for r, fi in enumerate(sel):
+                if st[r] == 0 and srs[r] == src_sr and nf[r] > 0 and int(math.ceil(int(nf[r]) * self.sr / src_sr)) <= L:
+                    frames[r], chans[r] = nf[r], ch[r]
+                    ok.append((r, fi))
+            meta[k] = ok
+            return (frames, chans), len(sel)
+
+        def upload(host, fc, slot, stream):
+            frames, chans = fc
+            if slot not in dev_out:
+                dev_out[slot] = torch.zeros(Bs, L, dtype=torch.float32, device=self.device)
+                dev_ws[slot] = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            d_pcm = host.to(self.device, non_blocking=True)
+            d_meta = torch.from_numpy(np.stack([frames, chans])).to(self.device)
+            rc = lib.wfl_resample_pcm16(C.c_void_p(d_pcm.data_ptr()), cap_in, C.c_void_p(d_meta[0].data_ptr()), C.c_void_p(d_meta[1].data_ptr()),
+                                        Bs, int(src_sr), int(self.sr), C.c_void_p(dev_out[slot].data_ptr()), L, L,
+                                        C.c_void_p(dev_ws[slot].data_ptr()), ws_bytes, C.c_void_p(stream.cuda_stream))
+            _lib.check(rc, "wfl_resample_pcm16")
+            d_pcm.record_stream(stream)
+            d_meta.record_stream(stream)
+            lens = np.minimum(np.ceil(frames.astype(np.float64) * self.sr / src_sr), L).astype(np.int32)
+            return dev_out[slot], lens
+
+        mode = self.config["postprocess"]["merge_segments"]
+        names = self._names_for(lang_name)[1]
+
+        def segments(rows):
+            res = []
+            for fi, ids, offs in rows:
+                s, e, ph = self._segments_of_item(ids, offs, lang_name)
+                ph = ph.astype(np.int32)
+                if mode != "none" and s.size:
+                    s, e, ph = npost.merge_segments(s, e, ph, mode)
+                res.append((fi, npost.to_tuples(s, e, ph, names)))
+            return res
+
+        def take(k, n, ids, offs):
+            futures.append(post.submit(segments, [(fi, ids[r].copy(), offs[r].copy()) for r, fi in meta.pop(k)]))
+
+        try:
+            self._run_batches((len(audio_paths) + Bs - 1) // Bs, fill, take, lang_id, threshold, pinned_in=pin, upload=upload)
+            for f in futures:
+                for fi, seg in f.result():
+                    done[fi] = seg
+        finally:
+            post.shutdown(wait=True)
+        return done
+
     def label_files(self, audio_paths, lang_id=None, confidence_threshold=0.0, verbose=True):
         """-> list (per file) of [(start_s, end_s, phoneme)] after merge + forced alignment."""
         if lang_id is not None and self.lang2id and lang_id > max(self.lang2id.values()):
@@ -360,6 +480,23 @@ class Labeler:
             if cand:
                 got = self._label_fast([audio_paths[fi] for fi in cand], lang_id, confidence_threshold, lang_name)
                 decided_fast = {cand[j]: seg for j, seg in got.items()}
+            # files at another rate: 16-bit PCM of at most 30 s goes to the GPU as it is and is resampled there (WFL_GPU_INGEST=0: host)
+            if os.environ.get("WFL_GPU_INGEST", "1") != "0":
+                by_rate = {}
+                for fi, p in enumerate(audio_paths):
+                    if fi in decided_fast:
+                        continue
+                    h = A.wav_header(p)
+                    if h is None:
+                        continue
+                    tag, ch, sr, bits, nbytes = h
+                    if tag == 1 and bits == 16 and ch in (1, 2) and sr != self.sr and sr > 0:
+                        frames = nbytes // (2 * ch)
+                        if 0 < frames and int(math.ceil(frames * self.sr / sr)) <= CHUNK_SAMPLES:
+                            by_rate.setdefault(sr, []).append(fi)
+                for sr, fis in by_rate.items():
+                    got = self._label_resampled([audio_paths[fi] for fi in fis], sr, lang_id, confidence_threshold, lang_name)
+                    decided_fast.update({fis[j]: seg for j, seg in got.items()})
         items, owner = [], []
         chunk_lens = []
 
