@@ -165,3 +165,28 @@ def test_wav_sample_rate_reads_the_header_only(tmp_path):
         f.write(b"not a wav file at all")
     assert A.wav_sample_rate(p) is None
     assert A.wav_sample_rate(str(tmp_path / "missing.wav")) is None
+
+
+def test_pcm16_reader_and_header_for_the_gpu_ingest_path(tmp_path):
+    """wfl_host_read_pcm16: the file's 16-bit samples as they are (interleaved), chunks before `data` skipped, odd chunk sizes padded;
+    other encodings / more than two channels / rows that are too short are turned away with the documented status."""
+    rng = np.random.RandomState(3)
+    x = (rng.randn(5000, 2) * 8000).astype("<i2")
+    p = str(tmp_path / "st.wav")
+    pcm = x.tobytes()
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) + b"LIST" + struct.pack("<I", 5) + b"abcde\x00" \
+        + b"data" + struct.pack("<I", len(pcm)) + pcm
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    assert A.wav_header(p) == (1, 2, 44100, 16, len(pcm))
+    pf = str(tmp_path / "f32.wav")
+    _raw_wav(pf, 3, 1, 22050, 32, np.zeros(10, np.float32).tobytes())
+    p3 = str(tmp_path / "c3.wav")
+    _raw_wav(p3, 1, 3, 16000, 16, np.zeros(30, "<i2").tobytes())
+    rows = np.full((5, 12000), 77, np.int16)
+    nf, ch, sr, st = A.read_pcm16_into([p, pf, p3, str(tmp_path / "missing.wav"), p], rows, 12000, threads=3)
+    assert list(st) == [0, 1, 2, 4, 0] and list(nf[[0, 4]]) == [5000, 5000] and list(ch[[0, 4]]) == [2, 2] and sr[0] == 44100
+    assert np.array_equal(rows[0, :10000].reshape(5000, 2), x) and np.array_equal(rows[4, :10000], rows[0, :10000])
+    assert (rows[0, 10000:] == 77).all()
+    nf, ch, sr, st = A.read_pcm16_into([p], rows, 9999, threads=1)             # one sample short
+    assert list(st) == [3] and nf[0] == 5000
+    assert A.wav_header(str(tmp_path / "missing.wav")) is None

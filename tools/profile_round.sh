@@ -22,6 +22,7 @@ P="--steps 10 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks1 -o cfg2_inflight1 -- $B $P --inflight 1 > $OUT/ks1.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2 -o cfg2_inflight2 -- $B $P --inflight 2 > $OUT/ks2.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf -o fullhead_inflight1 -- $B $P --inflight 1 --full-head > $OUT/ksf.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks5 -o cfg5_inflight1 -- $B --steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --config-index 4 > $OUT/ks5.log 2>&1 || exit 1
 echo "== pmc"
 P4="--steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B $P4 > $OUT/pmc_fetch.log 2>&1 || exit 1
@@ -30,6 +31,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_C
 echo "== files -> .lab end to end"
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 2> /dev/null | tail -1 > $OUT/e2e_label_files.txt || exit 1
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --full-head --files 768 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
+timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 --rate 44100 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
+WFL_GPU_INGEST=0 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 256 --rate 44100 2> /dev/null | tail -1 | sed 's/^/(WFL_GPU_INGEST=0: host resampler) /' >> $OUT/e2e_label_files.txt || exit 1
+timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --wavlm --files 512 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
 echo "== lstm micro"
 if [ $ROOT/wfl-asr_amd/csrc/lstm.hip -nt $ROOT/tools/micro/lstm_bench_x ] || [ ! -x $ROOT/tools/micro/lstm_bench_x ]; then
   echo "micro-benchmarks older than lstm.hip: rebuilding"; bash $ROOT/tools/micro/build.sh || exit 1

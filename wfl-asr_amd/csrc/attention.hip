@@ -383,7 +383,10 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   }
   switch (hd) {
     case 32: return launch_attn<32, 2, true, false>(a, s);
-    case 64: return launch_attn<64, 2, true, false>(a, s);
+    // head_dim 64 at cfg2 size (tools/attn_bench.py 512 8 16; WFL_ATTN_VARIANT=2 / 3: 16 / 64 queries per wave): see DESIGN.md section 4
+    case 64: return attn_variant() == 2 ? launch_attn<64, 1, true, false>(a, s)
+                  : attn_variant() == 3 ? launch_attn<64, 4, true, false>(a, s)
+                  : attn_variant() == 4 ? launch_attn<64, 3, true, false>(a, s) : launch_attn<64, 2, true, false>(a, s);
     case 128: return launch_attn<128, 2, true, false>(a, s);
     // head_dim 256, measured at cfg2 size (tools/attn_bench.py): <256, 1, no prefetch> 125 us (two workgroups per CU hide each other's
     // tile loads); <256, 2, prefetch> 166; <256, 2, no prefetch> 168; <256, 1, prefetch> 212 (one workgroup per CU each)

@@ -637,7 +637,7 @@ static int launch_stream(const GemmArgs& a, hipStream_t s) {
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
-  g_wfl_gemm_kernel_id = CONV ? 6 : (W8 ? 7 : (MT == 6 ? 1 : 5));     // (7: both fp8 forms)
+  g_wfl_gemm_kernel_id = CONV ? 6 : ((W8 || A8) ? 7 : (MT == 6 ? 1 : 5));     // (7: both fp8 forms)
   hipLaunchKernelGGL(k, dim3(tiles < SNCU ? tiles : SNCU), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

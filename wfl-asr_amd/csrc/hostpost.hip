@@ -361,24 +361,48 @@ int read_pcm16_one(const char* path, int16_t* out, long cap_samples, int32_t* n_
   *n_frames = 0; *channels = 0; *sr_out = 0;
   FILE* f = fopen(path, "rb");
   if (!f) return 4;
-  std::vector<unsigned char> d;
+  // walk the chunk headers (parse_wav's rules: the last `data` chunk counts) and read the samples STRAIGHT into the caller's row -- the
+  // row is pinned memory on the product path, so the file's bytes are copied once
+  unsigned char h[12];
+  if (fread(h, 1, 12, f) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) { fclose(f); return 1; }
   fseek(f, 0, SEEK_END);
-  const long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  if (sz > 0) { d.resize((size_t)sz); if (fread(d.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return 4; } }
-  fclose(f);
-  WavInfo w;
-  if (!parse_wav(d, w)) return 1;
-  *sr_out = w.sr;
-  if (w.tag != 1 || w.bits != 16 || w.ch < 1) return 1;
-  if (w.ch > 2) return 2;
-  const size_t total = w.pcm_bytes / 2;
-  const size_t frames = total / (size_t)w.ch;
-  *channels = w.ch;
+  const long fsz = ftell(f);
+  long pos = 12, data_pos = -1;
+  size_t data_bytes = 0;
+  int tag = 0, ch = 0, sr = 0, bits = 0;
+  bool have_fmt = false;
+  auto u16 = [](const unsigned char* q) { return (unsigned)q[0] | ((unsigned)q[1] << 8); };
+  auto u32 = [](const unsigned char* q) { return (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24); };
+  while (pos + 8 <= fsz) {
+    unsigned char ck[8];
+    if (fseek(f, pos, SEEK_SET) || fread(ck, 1, 8, f) != 8) break;
+    const size_t size = u32(ck + 4);
+    const long body = pos + 8;
+    const size_t avail = body <= fsz ? std::min<size_t>(size, (size_t)(fsz - body)) : 0;
+    if (!memcmp(ck, "fmt ", 4) && avail >= 16) {
+      unsigned char fm[40];
+      const size_t want = std::min<size_t>(avail, sizeof(fm));
+      if (fread(fm, 1, want, f) != want) break;
+      tag = (int)u16(fm); ch = (int)u16(fm + 2); sr = (int)u32(fm + 4); bits = (int)u16(fm + 14);
+      if (tag == 0xFFFE && want >= 26) tag = (int)u16(fm + 24);
+      have_fmt = true;
+    } else if (!memcmp(ck, "data", 4)) {
+      data_pos = body; data_bytes = avail;
+    }
+    pos += 8 + (long)size + (long)(size & 1);
+  }
+  if (!have_fmt || data_pos < 0) { fclose(f); return 1; }
+  *sr_out = sr;
+  if (tag != 1 || bits != 16 || ch < 1) { fclose(f); return 1; }
+  if (ch > 2) { fclose(f); return 2; }
+  const size_t frames = data_bytes / 2 / (size_t)ch;
+  *channels = ch;
   *n_frames = (int32_t)std::min<size_t>(frames, 0x7fffffff);
-  if ((long)(frames * (size_t)w.ch) > cap_samples) return 3;
-  memcpy(out, w.pcm, frames * (size_t)w.ch * 2);
-  return 0;
+  if ((long)(frames * (size_t)ch) > cap_samples) { fclose(f); return 3; }
+  const size_t nbytes = frames * (size_t)ch * 2;
+  const bool ok = fseek(f, data_pos, SEEK_SET) == 0 && fread(out, 1, nbytes, f) == nbytes;
+  fclose(f);
+  return ok ? 0 : 4;
 }
 
 // status: 0 ok; 1 not a WAV / unsupported encoding; 2 more than 2 channels; 3 longer than cap; 4 cannot open

@@ -38,9 +38,11 @@ struct ResampleArgs {
   int out_cap;
 };
 
+// (x / 32768.0 and x / 2.0 as multiplications by 2^-15 and 2^-1: exact, hence the same values as decode_mono's divisions, without 35
+//  float64 divisions per output sample)
 static __device__ __forceinline__ double pcm_sample(const int16_t* row, int ch, long idx) {
-  if (ch == 1) return (double)row[idx] / 32768.0;
-  return ((double)row[2 * idx] / 32768.0 + (double)row[2 * idx + 1] / 32768.0) / 2.0;
+  if (ch == 1) return (double)row[idx] * (1.0 / 32768.0);
+  return ((double)row[2 * idx] * (1.0 / 32768.0) + (double)row[2 * idx + 1] * (1.0 / 32768.0)) * 0.5;
 }
 
 __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs p) {
@@ -97,15 +99,15 @@ __global__ void clear_peaks_kernel(unsigned long long* peak, int B) {
 std::mutex g_tab_mu;
 std::vector<ResampleTable> g_tabs;
 
-// host: the taps of hostpost.hip:resample_f64, phase by phase
-const ResampleTable* table_for(int orig_freq, int new_freq) {
+// host: the taps of hostpost.hip:resample_f64, phase by phase.  (Returned BY VALUE: the cache is a vector that grows.)
+bool table_for(int orig_freq, int new_freq, ResampleTable& out) {
   int a = orig_freq, b = new_freq;
   while (b) { const int t = a % b; a = b; b = t; }
   const int orig = orig_freq / a, nw = new_freq / a;
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(g_tab_mu);
-  for (const auto& t : g_tabs) if (t.orig == orig && t.nw == nw && t.dev == dev) return &t;
+  for (const auto& t : g_tabs) if (t.orig == orig && t.nw == nw && t.dev == dev) { out = t; return true; }
   const double lpw = 6.0, rolloff = 0.99;
   const double base = (double)std::min(orig, nw) * rolloff;
   const int width = (int)std::ceil(lpw * orig / base);
@@ -123,7 +125,7 @@ const ResampleTable* table_for(int orig_freq, int new_freq) {
     cnt[i] = hi >= lo ? hi - lo + 1 : 0;
     maxcnt = std::max(maxcnt, cnt[i]);
   }
-  if (maxcnt == 0) return nullptr;
+  if (maxcnt == 0) return false;
   std::vector<double> kern((size_t)nw * maxcnt, 0.0);
   for (int i = 0; i < nw; ++i)
     for (int q = 0; q < cnt[i]; ++q) {
@@ -139,13 +141,14 @@ const ResampleTable* table_for(int orig_freq, int new_freq) {
   T.orig = orig; T.nw = nw; T.width = width; T.maxcnt = maxcnt; T.dev = dev;
   if (hipMalloc(&T.jlo, nw * sizeof(int)) != hipSuccess || hipMalloc(&T.cnt, nw * sizeof(int)) != hipSuccess ||
       hipMalloc(&T.kern, kern.size() * sizeof(double)) != hipSuccess)
-    return nullptr;
+    return false;
   if (hipMemcpy(T.jlo, jlo.data(), nw * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(T.cnt, cnt.data(), nw * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(T.kern, kern.data(), kern.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-    return nullptr;
+    return false;
   g_tabs.push_back(T);
-  return &g_tabs.back();
+  out = T;
+  return true;
 }
 
 }  // namespace
@@ -163,8 +166,9 @@ int32_t wfl_resample_pcm16(const int16_t* pcm, int64_t ld_in, const int32_t* n_i
   if (!pcm || !n_in || !channels || !out || !workspace || B <= 0 || orig_sr <= 0 || new_sr <= 0 || orig_sr == new_sr || out_cap <= 0 ||
       ld_out < out_cap || workspace_bytes < wfl_resample_workspace_bytes(B, out_cap))
     return -1;
-  const ResampleTable* T = table_for(orig_sr, new_sr);
-  if (!T) return -2;
+  ResampleTable Tv;
+  if (!table_for(orig_sr, new_sr, Tv)) return -2;
+  const ResampleTable* T = &Tv;
   hipStream_t s = (hipStream_t)stream;
   const long ld_tmp = ((long)out_cap + 31) / 32 * 32;
   ResampleArgs a{};

@@ -156,11 +156,12 @@ struct Twiddle { int nfft = 0, dev = -1, nbins = 0, nb_pad = 0; float* Wc = null
 std::mutex g_tw_mu;
 std::vector<Twiddle> g_tw;
 
-const Twiddle* twiddles(int nfft) {
+// (returned BY VALUE: the cache is a vector that grows, a pointer into it would dangle after the next table is added)
+bool twiddles(int nfft, Twiddle& out) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(g_tw_mu);
-  for (const auto& t : g_tw) if (t.nfft == nfft && t.dev == dev) return &t;
+  for (const auto& t : g_tw) if (t.nfft == nfft && t.dev == dev) { out = t; return true; }
   Twiddle T;
   T.nfft = nfft; T.dev = dev; T.nbins = nfft / 2 + 1; T.nb_pad = (T.nbins + 31) / 32 * 32;
   std::vector<float> wc((size_t)nfft * T.nb_pad, 0.f), ws((size_t)nfft * T.nb_pad, 0.f);
@@ -172,12 +173,13 @@ const Twiddle* twiddles(int nfft) {
       ws[(size_t)n * T.nb_pad + k] = (float)(-hann * std::sin(ang));
     }
   }
-  if (hipMalloc(&T.Wc, wc.size() * 4) != hipSuccess || hipMalloc(&T.Ws, ws.size() * 4) != hipSuccess) return nullptr;
+  if (hipMalloc(&T.Wc, wc.size() * 4) != hipSuccess || hipMalloc(&T.Ws, ws.size() * 4) != hipSuccess) return false;
   if (hipMemcpy(T.Wc, wc.data(), wc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(T.Ws, ws.data(), ws.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-    return nullptr;
+    return false;
   g_tw.push_back(T);
-  return &g_tw.back();
+  out = T;
+  return true;
 }
 
 template <int NFFT>
@@ -209,9 +211,8 @@ int32_t wfl_boundary_features(const float* wav, int64_t ldw, const int32_t* lens
       workspace_bytes < wfl_boundary_workspace_bytes(B, L))
     return -1;
   hipStream_t s = (hipStream_t)stream;
-  const Twiddle* t512 = twiddles(512);
-  const Twiddle* t2048 = twiddles(2048);
-  if (!t512 || !t2048) return -2;
+  Twiddle t512, t2048;
+  if (!twiddles(512, t512) || !twiddles(2048, t2048)) return -2;
   const int F = 1 + L / SHOP;
   float* S = (float*)workspace;                                  // [B][F][257] magnitude
   float* P = S + (size_t)B * F * 257;                            // [B][F][1025] power
@@ -219,9 +220,9 @@ int32_t wfl_boundary_features(const float* wav, int64_t ldw, const int32_t* lens
   unsigned* cmax = (unsigned*)(((uintptr_t)(LM + (size_t)B * F * 128) + 255) / 256 * 256);
   StftArgs a{};
   a.wav = wav; a.ldw = ldw; a.lens = lens; a.L = L; a.B = B; a.n_frames = F;
-  a.Wc = t512->Wc; a.Ws = t512->Ws; a.nbins = 257; a.nb_pad = t512->nb_pad; a.out = S; a.power = 0;
+  a.Wc = t512.Wc; a.Ws = t512.Ws; a.nbins = 257; a.nb_pad = t512.nb_pad; a.out = S; a.power = 0;
   if (int r = launch_stft<512>(a, s)) return r;
-  a.Wc = t2048->Wc; a.Ws = t2048->Ws; a.nbins = 1025; a.nb_pad = t2048->nb_pad; a.out = P; a.power = 1;
+  a.Wc = t2048.Wc; a.Ws = t2048.Ws; a.nbins = 1025; a.nb_pad = t2048.nb_pad; a.out = P; a.power = 1;
   if (int r = launch_stft<2048>(a, s)) return r;
   const long rows = (long)B * F;
   hipLaunchKernelGGL(flux_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, B, F, 257, flux);
