@@ -34,12 +34,17 @@ def _segments(ids, offsets, labels):
 
 
 @pytest.mark.parametrize("target,head,n_clips", [("fp32_weights", "cfg2", N_CLIPS), ("bf16_weights", "cfg2", N_CLIPS),
-                                                 ("bf16_weights", "default_head", 8)])
+                                                 ("bf16_weights", "default_head", 8), ("fp32_weights_precision_high", "cfg2", N_CLIPS)])
 def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
     """head = cfg2: BASELINE configs[1] (Whisper-base + 2 Conformer), all 64 clips.  head = default_head: the reference's default
     config.yaml head (2-layer BiLSTM + 2 Conformer + 2 dilated convs) on the first 8 clips of the same set -- the oracle's BiLSTM is
     a Python time loop, 8 clips keep it under a minute."""
     cfg = synth.baseline_config(1) if head == "cfg2" else synth.base_config("whisper")
+    high = target.endswith("precision_high")
+    if high:
+        # `model.precision: high` (round 3): every GEMM as three bf16 passes over split operands, fp32 sums, hi + lo activations --
+        # the switch for callers who need the reference's `.lab`; held to the reference on the checkpoint as given at a tenth of tau
+        cfg["model"]["precision"] = "high"
     cfg["output"]["save_dir"] = str(tmp_path)
     cfg["postprocess"] = {"median_filter": 1, "merge_segments": "right", "confidence_threshold": THR}
     labels = synth.make_labels(70)
@@ -48,7 +53,7 @@ def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
     sd_np = synth.make_state_dict(cfg, len(labels), seed=SEED)
     if target == "bf16_weights":
         sd_np = synth.round_weights_bf16(sd_np)
-    tau, band = (TAU_W, BAND_W) if target == "bf16_weights" else (TAU, BAND)
+    tau, band = (TAU_W, BAND_W) if target == "bf16_weights" else ((0.05, 0.01) if high else (TAU, BAND))
     # mixed lengths 1-30 s (a few exactly 30 s, a few very short), peak-normalised like infer.py:235 by the generator
     u = synth.uniform01("heldout.len", N_CLIPS, SEED)[:n_clips]
     secs = np.where(u < 0.1, 30.0, np.where(u > 0.9, 1.0 + 2.0 * u, 1.0 + 29.0 * u))
@@ -88,7 +93,9 @@ def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
           clips_with_identical_label_sequence=same_seq, reference_segments=n_seg, max_boundary_shift_s=shift)
     assert graded_bad == 0
     assert worst <= 0.02
-    if head != "cfg2":
+    if high:
+        assert raw_bad / frames < 0.002 and graded / frames >= 0.95 and same_seq >= (55 * n_clips) // 64, (raw_bad / frames, graded / frames, same_seq)
+    elif head != "cfg2":
         assert graded / frames >= 0.50 and raw_bad / frames < 0.04
     elif target == "bf16_weights":
         assert graded / frames >= 0.75 and raw_bad / frames < 0.02

@@ -337,6 +337,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[qt][dt][e] * inv);
         *(bf16x4*)(op + dt * 16) = ov;
+        if (p.O_lo) {                                 // (precision: high) what the rounding left behind
+          bf16x4 ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ol[e] = f2bf(o[qt][dt][e] * inv - bf2f(ov[e]));
+          *(bf16x4*)(p.O_lo + (op - p.O) + dt * 16) = ol;
+        }
       }
     }
   }

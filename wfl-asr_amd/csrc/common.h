@@ -99,6 +99,7 @@ struct AttnArgs {
   const float* bias;      // optional additive score bias (WavLM gated rel-pos), see attention.hip
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
   const int* clip_T;      // [B] valid frames per clip (keys and queries >= clip_T[b] do not exist), or null: T for all
+  bf16_t* O_lo;           // optional low half of the context (ld = ldo): o - bf16(o), for the split-precision GEMM that consumes it
   // fp8 context (BASELINE configs[4], round 3): instead of O, e4m3(context * o8_scale) goes to O8 (ldo8 bytes per row, same row mapping)
   // -- the out-projection's fp8 operand, with the fixed scale 1 / o8_scale (GemmArgs::a8_static).  head_dim 64 only.
   unsigned char* O8;

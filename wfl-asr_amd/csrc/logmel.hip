@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogmelArgs p) {
 
 __global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restrict__ raw, const unsigned* __restrict__ clipmax,
                                                             int B, int n_frames, int n_mels, bf16_t* __restrict__ out,
-                                                            long ldo, long lead, int P, float* __restrict__ ref_out) {
+                                                            long ldo, long lead, int P, float* __restrict__ ref_out, bf16_t* __restrict__ out_lo) {
   const long total = (long)B * n_frames * n_mels;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int m = (int)(i % n_mels);
@@ -208,7 +208,11 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restr
     const int t = (int)(bf % n_frames), b = (int)(bf / n_frames);
     const float floorv = ord2f(clipmax[b]) - 8.0f;
     const float v = (fmaxf(raw[i], floorv) + 4.0f) / 4.0f;
-    if (out) out[(lead + (long)b * P + t) * ldo + m] = f2bf(v);
+    if (out) {
+      const bf16_t hv = f2bf(v);
+      out[(lead + (long)b * P + t) * ldo + m] = hv;
+      if (out_lo) out_lo[(lead + (long)b * P + t) * ldo + m] = f2bf(v - bf2f(hv));     // (precision: high: the stem's split-precision operand)
+    }
     if (ref_out) ref_out[((long)b * n_mels + m) * n_frames + t] = v;
   }
 }
@@ -256,7 +260,7 @@ int wfl_launch_melpower(const LogmelArgs& a, int hop, bf16_t* out, long ldo, lon
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s) {
+int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s, bf16_t* out_lo) {
   if (a.n_frames * 160 != a.n_samples || a.n_mels <= 0 || a.B <= 0) return -1;
   if (wfl_launch_fill_i32((int*)a.clipmax, a.B, 0, s)) return -3;          // (a kernel, not a memset node: common.h)
   if (int r = launch_power<160, false>(a, s)) return r;
@@ -264,6 +268,6 @@ int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(logmel_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.raw, a.clipmax, a.B, a.n_frames,
-                     a.n_mels, out, ldo, lead, P, ref_out);
+                     a.n_mels, out, ldo, lead, P, ref_out, out_lo);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -26,7 +26,20 @@ struct LogmelArgs {
   float* raw;
   unsigned* clipmax;
 };
-int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s);
+int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s, bf16_t* out_lo = nullptr);
+struct PreciseFinishArgs {                 // precise.hip ("model.precision: high")
+  const float* acc; long ld_acc;
+  int B, P, T, n_out;
+  int glu;
+  const float* bias;
+  const float* clip_bias; const int* clip_idx; int clip_ld;
+  int act; float alpha;
+  const bf16_t* pos; long ldpos;
+  const bf16_t* res; const bf16_t* res_lo; long ldres;
+  bf16_t* out; bf16_t* out_lo; long ldc; long c_lead; int c_pitch;
+  const int* clip_T;
+};
+int wfl_launch_precise_finish(const PreciseFinishArgs& a, hipStream_t s);
 int wfl_launch_melpower(const LogmelArgs& a, int hop, bf16_t* out, long ldo, long lead, int P, int split, int shift, hipStream_t s);
 
 struct TagArgs {
@@ -134,6 +147,7 @@ struct Lin {
   int N = 0, K = 0, n_valid = 0;
   float* ln_s = nullptr; // set on a LayerNorm-folded operand: s[n] = sum_k W'[n][k] (gemm_stream.hip), bias = b + W beta
   float* w8 = nullptr;   // set on an fp8 operand: W holds OCP e4m3 bytes [N][K], w8[n] = the row's scale (GemmArgs::w8_scale)
+  bf16_t* W_lo = nullptr; // "model.precision: high": bf16(w - bf16(w)), same layout as W (precise.hip)
 };
 struct LNp { float* g = nullptr; float* b = nullptr; };
 
@@ -353,6 +367,18 @@ struct Packer {
     for (int n = 0; n < n_valid; ++n)
       for (int k = 0; k < k_valid; ++k) w[(size_t)n * L.K + k] = f32_to_bf16_bits(rows[(size_t)n * k_valid + k]);
     L.W = (bf16_t*)upload(w);
+    if (m->a.precision) {                      // the weights' low halves for the split-precision passes (precise.hip)
+      std::vector<uint16_t> wl((size_t)L.N * L.K, 0);
+      for (int n = 0; n < n_valid; ++n)
+        for (int k = 0; k < k_valid; ++k) {
+          const float x = rows[(size_t)n * k_valid + k];
+          const uint32_t u = (uint32_t)w[(size_t)n * L.K + k] << 16;
+          float xh;
+          memcpy(&xh, &u, 4);
+          wl[(size_t)n * L.K + k] = f32_to_bf16_bits(x - xh);
+        }
+      L.W_lo = (bf16_t*)upload(wl);
+    }
     std::vector<float> b((size_t)L.N, 0.f);
     if (bias) for (int n = 0; n < n_valid; ++n) b[n] = (*bias)[n];
     L.bias = upload(b);
@@ -1066,6 +1092,8 @@ struct Plan {
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
   long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, QKp, ATTp, clipT, total;
   long X8, FF8, rs8;            // fp8 activations (fp8_weights models): e4m3 rows [R][d], [R][ffw], fp32 row scales [R]
+  long lo_delta, hp32;          // "model.precision: high": every activation buffer has its low half lo_delta bytes further on (a twin of
+  long hp32_floats;             //   the whole activation area); hp32 = the fp32 sums of the three passes, [rows][columns]
   int da;                       // Conformer attention width (wfl_model::conf_da); QKp / ATTp exist when it differs from d
 };
 
@@ -1155,6 +1183,13 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   }
   p.clipT = take(8L * B * 4);                            // per-clip frame counts per front-end level (ragged batches), [level][B]
   p.err = take(256);                                     // the forward's device-side error word
+  if (a.precision) {
+    p.lo_delta = round_up(off, 256);
+    off = 2 * p.lo_delta;                                // the twin
+    const long rows = std::max(p.R2, p.R), cols = std::max<long>(std::max<long>(3L * std::max(p.d, p.da), 2L * p.ffw), 1024);
+    p.hp32_floats = rows * cols;
+    p.hp32 = take(p.hp32_floats * 4);
+  }
   p.total = off;
   return p;
 }
@@ -1197,8 +1232,20 @@ struct Runner {
   }
   // Residual stream hi + lo (common.h, GemmArgs::res_lo): X and Y have low halves; lo_ok says whether the low half of the
   // tensor currently held in X / Y is valid (a kernel that writes only the high half invalidates it).
-  bool lo_ok[2] = {false, false};
-  int lo_idx(const void* ptr) const {               // 0: inside X's first row (a column offset is allowed), 1: Y, else -1
+  // "model.precision: high" (precise.hip): EVERY activation buffer has a low half, lo_delta bytes further on, and lo_ok tracks the
+  // buffers whose producer wrote it (X, Y, ATT, QK, FF, mel, c1, enc2, QKp, ATTp: indices 0 .. 9; any pointer inside the buffer counts)
+  bool precise() const { return m->a.precision != 0 && p.lo_delta > 0; }
+  bool lo_ok[10] = {false, false, false, false, false, false, false, false, false, false};
+  int lo_idx(const void* ptr) const {               // default mode -- 0: inside X's first row (a column offset is allowed), 1: Y, else -1
+    if (precise()) {
+      const long o = (const char*)ptr - ws;
+      const long st[10] = {p.X, p.Y, p.ATT, p.QK, p.FF, p.mel, p.c1, p.enc2, p.QKp, p.ATTp};
+      const long sz[10] = {p.R * p.d * 2, p.R * p.d * 2, p.R * p.d * 2, p.R * 3L * p.d * 2, p.R * (long)p.ffw * 2, p.mel > 0 || m->a.encoder_type == WFL_ENC_WHISPER ? p.R2 * m->a.n_mels * 2 + 1024 : 0,
+                           m->a.encoder_type == WFL_ENC_WHISPER ? p.R2 * (long)p.d * 2 : 0, p.R * p.d * 2, p.da != p.d ? p.R * 3L * p.da * 2 : 0, p.da != p.d ? p.R * (long)p.da * 2 : 0};
+      for (int i = 0; i < 10; ++i)
+        if (sz[i] > 0 && o >= st[i] && o < st[i] + sz[i]) return i;
+      return -1;
+    }
     const long dx = (const char*)ptr - (ws + p.X), dy = (const char*)ptr - (ws + p.Y);
     if (dx >= 0 && dx < (long)p.d * 2) return 0;
     if (dy >= 0 && dy < (long)p.d * 2) return 1;
@@ -1207,6 +1254,7 @@ struct Runner {
   bf16_t* lo_of(const void* ptr) const {
     const int i = lo_idx(ptr);
     if (i < 0) return nullptr;
+    if (precise()) return (bf16_t*)((char*)ptr + p.lo_delta);
     return (bf16_t*)(ws + (i == 0 ? p.Xlo : p.Ylo) + ((const char*)ptr - (ws + (i == 0 ? p.X : p.Y))));
   }
   const bf16_t* lo_in(const void* ptr) const { const int i = lo_idx(ptr); return (i >= 0 && lo_ok[i]) ? lo_of(ptr) : nullptr; }
@@ -1232,6 +1280,11 @@ struct Runner {
             const bf16_t* pos = nullptr, long ldpos = 0, const float* clip_bias = nullptr, const int* clip_idx = nullptr,
             int clip_ld = 0) {
     if (rc) return;
+    if (precise() && !out_f32 && !W.w8 && !next_a8 && W.W_lo) {
+      gemm_precise(A, lda, W, M, P, T, C, ldc, c_lead, c_pitch, act, res, ldres, alpha, cin, tap_stride, glu, pos, ldpos, clip_bias, clip_idx,
+                   clip_ld);
+      return;
+    }
     GemmArgs g{};
     g.ln_s = W.ln_s; g.ln_eps = 1e-5f;
     g.w8_scale = W.w8;
@@ -1291,6 +1344,64 @@ struct Runner {
     if (r) rc = fail(r, "gemm launch failed (" + std::to_string(r) + ")");
   }
 
+  // "model.precision: high": the same Linear / Conv1d as three bf16 passes over split operands, summed in fp32, then the layer's
+  // epilogue as its own kernel (precise.hip).  A's low half is used when its producer wrote it (lo_ok).
+  void gemm_precise(const bf16_t* A, long lda, const Lin& W, int M, int P, int T, void* C, long ldc, long c_lead, int c_pitch, int act,
+                    const bf16_t* res, long ldres, float alpha, int cin, long tap_stride, bool glu, const bf16_t* pos, long ldpos,
+                    const float* clip_bias, const int* clip_idx, int clip_ld) {
+    next_lo_out = next_acc_f32 = next_stats = false;
+    next_flops = -1.0;
+    stats_in_next = false;
+    if (C == stats_for) stats_for = nullptr;
+    const int B = M / P;
+    if ((long)M * W.N > p.hp32_floats) { rc = fail(-1, "precision high: the fp32 accumulator is too small for this launch"); return; }
+    float* acc = (float*)(ws + p.hp32);
+    const bf16_t* A_lo = lo_in(A);
+    for (int pass = 0; pass < 3; ++pass) {
+      if (pass == 2 && !A_lo) break;
+      GemmArgs g{};
+      g.A = pass == 2 ? A_lo : A; g.lda = lda;
+      g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
+      g.W = pass == 1 ? W.W_lo : W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.N;
+      g.P = P; g.T = T; g.clip_T = clip_T_for(P);
+      g.C = acc; g.ldc = W.N; g.c_lead = 0; g.c_pitch = P;
+      g.alpha = 1.f; g.act = WFL_ACT_NONE; g.out_f32 = 1; g.acc_f32 = pass > 0 ? 1 : 0;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (m->prof_on) {
+        if (m->prof_used >= m->prof.ev.size()) {
+          hipEvent_t a_, b_;
+          if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) { rc = fail(-10, "hipEventCreate"); return; }
+          m->prof.ev.push_back({a_, b_});
+        }
+        e0 = m->prof.ev[m->prof_used].first; e1 = m->prof.ev[m->prof_used].second;
+        ++m->prof_used;
+        (void)hipEventRecord(e0, s);
+      }
+      const int r = wfl_launch_gemm(g, s);
+      if (m->prof_on) {
+        (void)hipEventRecord(e1, s);
+        const int key = 8 | ((g_wfl_gemm_kernel_id & 7) << 5);
+        m->prof.key.push_back(key);
+        m->prof.launches[key] += 1;
+        m->prof.flops[key] += 2.0 * (double)B * T * (double)W.n_valid * (double)W.K;
+      }
+      if (r) { rc = fail(r, "gemm launch failed (precision high, pass " + std::to_string(pass) + ": " + std::to_string(r) + ")"); return; }
+    }
+    PreciseFinishArgs f{};
+    f.acc = acc; f.ld_acc = W.N; f.B = B; f.P = P; f.T = T;
+    f.glu = glu ? 1 : 0;
+    f.n_out = glu ? W.n_valid / 2 : W.n_valid;
+    f.bias = W.bias; f.clip_bias = clip_bias; f.clip_idx = clip_idx; f.clip_ld = clip_ld;
+    f.act = act; f.alpha = alpha; f.pos = pos; f.ldpos = ldpos;
+    f.res = res; f.res_lo = res ? lo_in(res) : nullptr; f.ldres = ldres;
+    f.out = (bf16_t*)C; f.out_lo = lo_of(C); f.ldc = ldc; f.c_lead = c_lead; f.c_pitch = c_pitch;
+    f.clip_T = clip_T_for(P);
+    { const int ci = lo_idx(C); if (ci >= 0) lo_ok[ci] = f.out_lo != nullptr; }
+    if (f.n_out % 8) { rc = fail(-1, "precision high: output width must be a multiple of 8"); return; }
+    const int r = wfl_launch_precise_finish(f, s);
+    if (r) rc = fail(r, "precise_finish launch failed");
+  }
+
   // WFL_LN_FOLD: 1 (default) fold a LayerNorm into the GEMM that consumes it whenever the GEMM that produced its input left
   // the row statistics behind; 2 fold always, summing the statistics inside the consumer (slower: tools/gemm_lab.py qkvLN);
   // 0 never (LayerNorm kernel + plain GEMM).
@@ -1303,7 +1414,8 @@ struct Runner {
   void ln_gemm(const bf16_t* x, bf16_t* scratch, const LNp& w, const Lin& plain, const Lin& folded, int M, void* C, long ldc,
                int act) {
     if (rc) return;
-    const int mode = m->dv != p.d ? 0 : ln_fold_mode();        // (the folded form divides by K: not for a zero-padded width)
+    const int mode = (m->dv != p.d || precise()) ? 0 : ln_fold_mode();   // (the folded form divides by K: not for a zero-padded width;
+                                                                          //  precision high: the LayerNorm kernel writes hi + lo)
     if (folded.ln_s && (mode == 2 || (mode == 1 && stats_for == x))) {
       GemmArgs g{};
       g.M = M; g.N = folded.N; g.K = folded.K; g.cin = folded.K; g.n_valid = folded.n_valid; g.act = act; g.ln_s = folded.ln_s;
@@ -1323,7 +1435,7 @@ struct Runner {
     if (rc) return;
     if (y == stats_for) stats_for = nullptr;
     const bf16_t* x_lo = lo_in(x);
-    bf16_t* y_lo = lo_out ? lo_of(y) : nullptr;
+    bf16_t* y_lo = (lo_out || precise()) ? lo_of(y) : nullptr;
     { const int yi = lo_idx(y); if (yi >= 0) lo_ok[yi] = y_lo != nullptr; }
     prof_begin();
     const int r = wfl_launch_layernorm_act(x, p.d, y, p.d, w.g, w.b, 1e-5f, p.lead, p.B, p.P, p.T, p.d, 0, s, x_lo, y_lo, m->dv, clipT);
@@ -1361,6 +1473,12 @@ struct Runner {
     AttnArgs a{};
     a.bias = bias; a.gate = gate;
     a.O8 = o8; a.ldo8 = ldo8; a.o8_scale = o8_scale;
+    if (precise() && !o8) {                               // the context's low half for the out-projection's third pass
+      bf16_t* o_hi = buf(padded ? p.ATTp : p.ATT);
+      a.O_lo = lo_of(o_hi);
+      const int oi = lo_idx(o_hi);
+      if (oi >= 0) lo_ok[oi] = a.O_lo != nullptr;
+    }
     const int w = padded ? p.da : p.d;
     bf16_t* qk = buf(padded ? p.QKp : p.QK);
     a.QK = qk; a.ldqk = 3 * w; a.lead = p.lead; a.V = qk + 2 * w; a.ldv = 3 * w; a.O = buf(padded ? p.ATTp : p.ATT); a.ldo = w;
@@ -1403,7 +1521,8 @@ static int run_logmel(wfl_model* m, const Plan& p, char* ws, const float* wav, l
   a.n_frames = p.T2; a.n_samples = p.T2 * 160; a.n_mels = m->a.n_mels;
   a.Wc = m->Wc; a.Ws = m->Ws; a.mel_lo = m->mel_lo; a.mel_cnt = m->mel_cnt; a.mel_w = m->mel_w; a.mel_maxw = m->mel_maxw;
   a.raw = (float*)(ws + p.raw); a.clipmax = (unsigned*)(ws + p.clipmax);
-  return wfl_launch_logmel(a, (bf16_t*)(ws + p.mel), m->a.n_mels, p.lead2, p.P2, ref_out, s);
+  bf16_t* mel_lo = (m->a.precision && p.lo_delta > 0) ? (bf16_t*)(ws + p.mel + p.lo_delta) : nullptr;
+  return wfl_launch_logmel(a, (bf16_t*)(ws + p.mel), m->a.n_mels, p.lead2, p.P2, ref_out, s, mel_lo);
 }
 
 int32_t wfl_logmel(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L, float* out,
@@ -1439,6 +1558,24 @@ static int begin_forward(Runner& R, bool with_encoder) {
     R.zero_add(p.c1, d, p.lead2, p.P2, p.T2, 2 * p.tail);
   }
   R.zero_flush();
+  if (R.precise()) {                               // the low halves' halo rows are taps of the split-precision convolutions too
+    const long D = p.lo_delta;
+    R.zero_add(p.X + D, d, p.lead, p.P, p.T, p.tail);
+    R.zero_add(p.Y + D, d, p.lead, p.P, p.T, p.tail);
+    R.zero_add(p.ATT + D, d, p.lead, p.P, p.T, p.tail);
+    R.zero_add(p.QK + D, 3 * d, p.lead, p.P, p.T, p.tail);
+    R.zero_add(p.FF + D, p.ffw, p.lead, p.P, p.T, p.tail);
+    if (p.da != d) {
+      R.zero_add(p.QKp + D, 3 * p.da, p.lead, p.P, p.T, p.tail);
+      R.zero_add(p.ATTp + D, p.da, p.lead, p.P, p.T, p.tail);
+    }
+    if (with_encoder && a.encoder_type == WFL_ENC_WHISPER) {
+      R.zero_add(p.mel + D, a.n_mels, p.lead2, p.P2, p.T2, 2 * p.tail);
+      R.zero_add(p.c1 + D, d, p.lead2, p.P2, p.T2, 2 * p.tail);
+    }
+    R.zm.err_word = nullptr;                       // (cleared by the first flush)
+    R.zero_flush();
+  }
   // a zero-padded width (encoder_type none): the front-end / wfl_head write only the valid columns of the Y rows
   if (!R.rc && R.m->dv != d && wfl_launch_fill_i32((int*)(R.ws + p.Y), p.R * d / 2, 0, R.s)) return fail(-3, "fill launch failed");
   return R.rc;
@@ -1459,6 +1596,14 @@ static int zero_shared_buffers(Runner& R) {
     r = wfl_launch_fill_i32((int*)(R.ws + p.QKp), p.R * 3L * p.da / 2, 0, R.s);
     if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.ATTp), p.R * (long)p.da / 2, 0, R.s);
   }
+  if (!r && R.precise()) {                         // ... and their low halves
+    const long D = p.lo_delta;
+    r = wfl_launch_fill_i32((int*)(R.ws + p.X + D), p.R * d / 2, 0, R.s);
+    if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.Y + D), p.R * d / 2, 0, R.s);
+    if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.ATT + D), p.R * d / 2, 0, R.s);
+    if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.QK + D), p.R * 3 * d / 2, 0, R.s);
+    if (!r) r = wfl_launch_fill_i32((int*)(R.ws + p.FF + D), p.R * (long)p.ffw / 2, 0, R.s);
+  }
   return r ? fail(r, "fill launch failed") : 0;
 }
 
@@ -1476,6 +1621,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     const int r = run_logmel(m, p, R.ws, wav, ldw, lens, nullptr, R.s);
     R.prof_end(2042, 0.96e9 * (double)B * (a.n_mels / 80.0));
     if (r) return fail(r, "logmel launch failed");
+    if (R.precise()) R.lo_ok[5] = true;                // (the log-mel kernel wrote the features' low half)
     bf16_t* mel = R.buf(p.mel);
     bf16_t* c1 = R.buf(p.c1);
     // conv1 k3 p1: frame t reads mel rows t-1..t+1 = 3*n_mels contiguous channels

@@ -92,6 +92,8 @@ class BIOPhonemeTagger:
             a.wavlm_pos_conv_kernel, a.wavlm_pos_conv_groups = w.pos_conv_kernel, w.pos_conv_groups
             a.wavlm_num_buckets, a.wavlm_max_distance = w.num_buckets, w.max_distance
             a.wavlm_do_normalize = int(w.do_normalize)
+        # model.precision: high -- split-precision GEMMs (three bf16 passes, fp32 sums) for callers who need the reference's tag indices
+        a.precision = int(str(config["model"].get("precision", "default")).lower() in ("high", "exact"))
         h = self.head_cfg
         a.num_classes, a.o_id = len(self.label_list), self.label2id["O"]
         a.num_languages, a.lang_emb_dim = h["num_languages"], h["lang_emb_dim"]
