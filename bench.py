@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight per GPU: step i runs on stream i %% inflight with its own workspace and host buffer")
     ap.add_argument("--config-index", type=int, default=1, help="BASELINE.json configs[] index (1..4)")
+    ap.add_argument("--precision", default="default", choices=["default", "high"],
+                    help="model.precision: high = every GEMM and the attention as three bf16 passes over split operands (the reference's tag indices)")
     ap.add_argument("--full-head", action="store_true",
                     help="Whisper-base + the reference's default config.yaml head (2-layer BiLSTM, 2 Conformer, 2 dilated convs)")
     return ap.parse_args()
@@ -184,6 +186,8 @@ def main():
     from wfl_asr_amd.dist import gather_packed
 
     cfg = synth.base_config("whisper") if args.full_head else synth.baseline_config(args.config_index)
+    if args.precision != "default":
+        cfg["model"]["precision"] = args.precision
     def_b, def_s = (16, 30.0) if args.full_head else CONFIG_SHAPE[args.config_index]
     B = args.batch or def_b
     clip_seconds = args.clip_seconds or def_s
@@ -389,7 +393,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp8 (e4m3 weights and activations in the encoder's GEMMs, v_mfma_f32_16x16x32_fp8_fp8; bf16 elsewhere)"
                       if os.environ.get("WFL_FP8_ACT", "1") != "0" else "bf16 (fp8 e4m3 encoder weights)")
-                     if str(m.get("weight_dtype", "bf16")) == "fp8" else "bf16", "data": "synthetic",
+                     if str(m.get("weight_dtype", "bf16")) == "fp8" else
+                     ("bf16 pairs (model.precision: high -- hi + lo operands, three MFMA passes, fp32 sums)" if args.precision == "high" else "bf16"),
+            "data": "synthetic",
             "config": {"workload": ("default config.yaml head: " if args.full_head else "BASELINE configs[%d]: " % args.config_index)
                        + "%s + %s%d Conformer blocks%s, %d x %g s clips per GPU" % (
                 enc_name, "%d-layer BiLSTM + " % m["bilstm_num_layer"] if m["enable_bilstm"] else "", m["num_conformer_layers"],

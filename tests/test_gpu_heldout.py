@@ -43,7 +43,8 @@ def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
     high = target.endswith("precision_high")
     if high:
         # `model.precision: high` (round 3): every GEMM as three bf16 passes over split operands, fp32 sums, hi + lo activations --
-        # the switch for callers who need the reference's `.lab`; held to the reference on the checkpoint as given at a tenth of tau
+        # (the attention too: q, k, v and P as bf16 pairs) -- the switch for callers who need the reference's `.lab`; held to the
+        # reference on the checkpoint as given at an eightieth of the default build's tau
         cfg["model"]["precision"] = "high"
     cfg["output"]["save_dir"] = str(tmp_path)
     cfg["postprocess"] = {"median_filter": 1, "merge_segments": "right", "confidence_threshold": THR}
@@ -53,7 +54,7 @@ def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
     sd_np = synth.make_state_dict(cfg, len(labels), seed=SEED)
     if target == "bf16_weights":
         sd_np = synth.round_weights_bf16(sd_np)
-    tau, band = (TAU_W, BAND_W) if target == "bf16_weights" else ((0.05, 0.01) if high else (TAU, BAND))
+    tau, band = (TAU_W, BAND_W) if target == "bf16_weights" else ((0.005, 0.002) if high else (TAU, BAND))
     # mixed lengths 1-30 s (a few exactly 30 s, a few very short), peak-normalised like infer.py:235 by the generator
     u = synth.uniform01("heldout.len", N_CLIPS, SEED)[:n_clips]
     secs = np.where(u < 0.1, 30.0, np.where(u > 0.9, 1.0 + 2.0 * u, 1.0 + 29.0 * u))
@@ -94,7 +95,10 @@ def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
     assert graded_bad == 0
     assert worst <= 0.02
     if high:
-        assert raw_bad / frames < 0.002 and graded / frames >= 0.95 and same_seq >= (55 * n_clips) // 64, (raw_bad / frames, graded / frames, same_seq)
+        # measured: 3 of 96 000 raw decisions differ (default build: 1.98 %); 62 of 64 clips give the reference's label sequence (default:
+        # 5) with boundaries within 50 us; offsets within 0.003
+        assert raw_bad / frames < 0.0005 and graded / frames >= 0.97 and same_seq >= (58 * n_clips) // 64, (raw_bad / frames, graded / frames, same_seq)
+        assert worst <= 0.004
     elif head != "cfg2":
         assert graded / frames >= 0.50 and raw_bad / frames < 0.04
     elif target == "bf16_weights":

@@ -41,11 +41,15 @@ static __device__ __forceinline__ int k_swz(int row) {
   return (row >> 2) & 3;                      // CPR == 4
 }
 
-template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false>
+// SPLIT ("model.precision: high", AttnArgs::QK_lo / V_lo): q, k, v arrive as bf16 pairs hi + lo and P is split in registers; the scores
+// and the context are three MFMA passes each (the products of two low halves are dropped: 2^-18 relative).  A tile holds four images.
+template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+  static_assert(!SPLIT || (!BIAS && !OUT8), "split precision: the plain kernels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VPITCH = HD * 2 + 32;
-  constexpr int TILE_BYTES = KT * HD * 2 + KT * VPITCH;   // K tile [KT][HD] (16-byte chunks XOR-swizzled) + V tile [KT][VPITCH]
+  constexpr int TILE1 = KT * HD * 2 + KT * VPITCH;          // K tile [KT][HD] (16-byte chunks XOR-swizzled) + V tile [KT][VPITCH]
+  constexpr int TILE_BYTES = SPLIT ? 2 * TILE1 : TILE1;     // SPLIT: the low halves' images behind the high ones
   // PREFETCH variants keep TWO tiles in LDS: tile kt+1 is written (from the registers its global loads landed in) right
   // after tile kt's MFMAs, so a key tile costs one workgroup barrier instead of two
   char* Ks = smem;
@@ -78,9 +82,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   const long row0 = p.lead + (long)b * p.P;
   const bf16_t* Kg = p.QK + p.d + h * HD;                 // + row * ldqk
   const bf16_t* Vg = p.V + h * HD;                        // + row * ldv
+  const bf16_t* Kgl = SPLIT ? p.QK_lo + p.d + h * HD : nullptr;
+  const bf16_t* Vgl = SPLIT ? p.V_lo + h * HD : nullptr;
 
   // ---- Q fragments (B operand): lane -> query frame q0 + 16*qt + c, channels 32*ks + 8*g .. +8
-  bf16x8 qf[QT][KS];
+  bf16x8 qf[QT][KS], qfl[SPLIT ? QT : 1][SPLIT ? KS : 1];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     int q = q0 + qt * 16 + c;
@@ -88,6 +94,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const bf16_t* qp = p.QK + (row0 + q) * p.ldqk + h * HD + g * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *(const bf16x8*)(qp + ks * 32);
+    if (SPLIT) {
+      const bf16_t* ql = p.QK_lo + (row0 + q) * p.ldqk + h * HD + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qfl[qt][ks] = *(const bf16x8*)(ql + ks * 32);
+    }
   }
 
   // Online softmax with a DEFERRED reference: scores are produced as s - mref (the S^T accumulators start at -mref, so
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
   const int ntiles = (T + KT - 1) / KT;
   bf16x8 kreg[KCH], vreg[KCH];
+  bf16x8 kregl[(SPLIT && PREFETCH) ? KCH : 1], vregl[(SPLIT && PREFETCH) ? KCH : 1];    // (non-prefetching kernels reuse kreg / vreg for the low tile)
 
   // per-lane element offsets inside a tile are fixed; the tile base is block-uniform (scalar base + 32-bit lane offset)
   int koff[KCH], voff[KCH];
@@ -130,6 +142,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       kreg[i] = *(const bf16x8*)(kb + koff[i]);
       vreg[i] = *(const bf16x8*)(vb + voff[i]);
     }
+    if (SPLIT && PREFETCH) {
+      const bf16_t* kl = Kgl + (row0 + (long)kt * KT) * p.ldqk;
+      const bf16_t* vl = Vgl + (row0 + (long)kt * KT) * p.ldv;
+#pragma unroll
+      for (int i = 0; i < KCH; ++i) {
+        kregl[i] = *(const bf16x8*)(kl + koff[i]);
+        vregl[i] = *(const bf16x8*)(vl + voff[i]);
+      }
+    }
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -138,6 +159,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       const int r = ch / CPR, cc = ch % CPR;
       *(bf16x8*)(Ks + r * (HD * 2) + ((cc ^ k_swz<HD>(r)) << 4)) = kreg[i];
       *(bf16x8*)(Vs + r * VPITCH + cc * 16) = vreg[i];
+      if (SPLIT && PREFETCH) {
+        *(bf16x8*)(Ks + TILE1 + r * (HD * 2) + ((cc ^ k_swz<HD>(r)) << 4)) = kregl[i];
+        *(bf16x8*)(Vs + TILE1 + r * VPITCH + cc * 16) = vregl[i];
+      }
+    }
+  };
+  auto load_store_lo = [&](int kt) {           // SPLIT without prefetch: the low tile through the same registers, after the high one
+    const bf16_t* kl = Kgl + (row0 + (long)kt * KT) * p.ldqk;
+    const bf16_t* vl = Vgl + (row0 + (long)kt * KT) * p.ldv;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      kreg[i] = *(const bf16x8*)(kl + koff[i]);
+      vreg[i] = *(const bf16x8*)(vl + voff[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int ch = tid + 256 * i;
+      const int r = ch / CPR, cc = ch % CPR;
+      *(bf16x8*)(Ks + TILE1 + r * (HD * 2) + ((cc ^ k_swz<HD>(r)) << 4)) = kreg[i];
+      *(bf16x8*)(Vs + TILE1 + r * VPITCH + cc * 16) = vreg[i];
     }
   };
 
@@ -177,6 +218,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       __syncthreads();                   // every wave is done reading the previous tile
       load_tile(kt);
       store_tile();
+      if (SPLIT) load_store_lo(kt);
       __syncthreads();
     } else {
       Ks = smem + (kt & 1) * TILE_BYTES;
@@ -198,6 +240,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           st[qt][kk] = attn_mfma(kf, qf[qt][ks], st[qt][kk]);
+        if (SPLIT) {
+          const bf16x8 kfl = *(const bf16x8*)(Ks + TILE1 + r * (HD * 2) + (((ks * 4 + g) ^ k_swz<HD>(r)) << 4));
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            st[qt][kk] = attn_mfma(kf, qfl[qt][ks], st[qt][kk]);
+            st[qt][kk] = attn_mfma(kfl, qf[qt][ks], st[qt][kk]);
+          }
+        }
       }
     }
     if (BIAS) {
@@ -223,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 
     // ---- softmax numerators (per query frame = per lane column c; the 4 lane groups g share a frame)
-    bf16x8 pf[QT][2];
+    bf16x8 pf[QT][2], pfl[SPLIT ? QT : 1][2];
     {
       float mx[QT];
       bool over = kt == 0;
@@ -275,6 +325,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         }
         pf[qt][s2] = t;
         osum[qt] = attn_mfma(ones, t, osum[qt]);
+        if (SPLIT) {                              // what the rounding of P left behind, as a second operand
+          bf16x8 tl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            tl[e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2][e]) - bf2f(t[e]));
+            tl[4 + e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2 + 1][e]) - bf2f(t[4 + e]));
+          }
+          pfl[qt][s2] = tl;
+          osum[qt] = attn_mfma(ones, tl, osum[qt]);
+        }
       }
     }
 
@@ -292,6 +352,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           o[qt][dt] = attn_mfma(vf, pf[qt][s2], o[qt][dt]);
+        if (SPLIT) {
+          const bf16x4 llo = ds_read_tr(vp + TILE1);
+          const bf16x4 lhi = ds_read_tr(vp + TILE1 + 16 * VPITCH);
+          const bf16x8 vfl = {llo[0], llo[1], llo[2], llo[3], lhi[0], lhi[1], lhi[2], lhi[3]};
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            o[qt][dt] = attn_mfma(vf, pfl[qt][s2], o[qt][dt]);
+            o[qt][dt] = attn_mfma(vfl, pf[qt][s2], o[qt][dt]);
+          }
+        }
       }
     }
     if (PREFETCH && kt + 1 < ntiles) {
@@ -348,11 +418,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 }
 
-template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false>
+template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   static_assert(!BIAS || PREFETCH, "the bias table slice is staged on the prefetch barrier");
-  constexpr int lds = (PREFETCH ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32)) + (BIAS ? 2 * (KT + 4 * QT * 16) * 4 : 0);
-  auto k = attn_kernel<HD, QT, PREFETCH, BIAS, OUT8>;
+  constexpr int lds = (PREFETCH ? 2 : 1) * (SPLIT ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32)) + (BIAS ? 2 * (KT + 4 * QT * 16) * 4 : 0);
+  auto k = attn_kernel<HD, QT, PREFETCH, BIAS, OUT8, SPLIT>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
@@ -378,6 +448,10 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.O8) {
     if (a.bias || hd != 64 || a.ldo8 % 4) return -4;
     return launch_attn<64, 2, true, false, true>(a, s);
+  }
+  if (a.QK_lo && a.V_lo && !a.bias && !a.O8) {          // "model.precision: high": three passes over split operands
+    if (hd == 64) return launch_attn<64, 2, true, false, false, true>(a, s);
+    if (hd == 256) return launch_attn<256, 1, false, false, false, true>(a, s);
   }
   if (a.bias) {
     if (!a.gate) return -1;

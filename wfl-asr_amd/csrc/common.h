@@ -100,6 +100,9 @@ struct AttnArgs {
   const float* gate;      // [B][heads][T] per-query gate multiplying bias[h][q][k]
   const int* clip_T;      // [B] valid frames per clip (keys and queries >= clip_T[b] do not exist), or null: T for all
   bf16_t* O_lo;           // optional low half of the context (ld = ldo): o - bf16(o), for the split-precision GEMM that consumes it
+  const bf16_t* QK_lo;    // "model.precision: high": the low halves of the packed q | k rows and of the v columns (same layout and leading
+  const bf16_t* V_lo;     //   dimensions as QK / V).  Both set: scores and context run as three MFMA passes over split operands
+                          //   (q_hi k_hi + q_lo k_hi + q_hi k_lo; p_hi v_hi + p_lo v_hi + p_hi v_lo, P split in registers); head_dim 64 / 256
   // fp8 context (BASELINE configs[4], round 3): instead of O, e4m3(context * o8_scale) goes to O8 (ldo8 bytes per row, same row mapping)
   // -- the out-projection's fp8 operand, with the fixed scale 1 / o8_scale (GemmArgs::a8_static).  head_dim 64 only.
   unsigned char* O8;

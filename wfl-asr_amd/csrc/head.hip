@@ -13,6 +13,7 @@ struct TagArgs {
   float* maxprob;
   // offsets (optional)
   const bf16_t* hid; long ldh; long lead; int P, T, d;   // frame rows of the offset head's hidden activation
+  const bf16_t* hid_lo;              //   precision high: their low halves (same layout) or null
   const float* w2;                   // [2][d]
   const float* b2;                   // [2]
   float* offsets;                    // [rows][2]
@@ -74,6 +75,15 @@ __global__ __launch_bounds__(256) void tag_decide_kernel(TagArgs p) {
         const float x = bf2f(hv[e]);
         a0 += x * p.w2[c0 + e];
         a1 += x * p.w2[p.d + c0 + e];
+      }
+      if (p.hid_lo) {
+        const bf16x8 lv = *(const bf16x8*)(p.hid_lo + (hp - p.hid) + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = bf2f(lv[e]);
+          a0 += x * p.w2[c0 + e];
+          a1 += x * p.w2[p.d + c0 + e];
+        }
       }
     }
 #pragma unroll

@@ -35,6 +35,7 @@ struct PreciseFinishArgs {                 // precise.hip ("model.precision: hig
   const float* clip_bias; const int* clip_idx; int clip_ld;
   int act; float alpha;
   const bf16_t* pos; long ldpos;
+  const bf16_t* pos_lo;
   const bf16_t* res; const bf16_t* res_lo; long ldres;
   bf16_t* out; bf16_t* out_lo; long ldc; long c_lead; int c_pitch;
   const int* clip_T;
@@ -50,6 +51,7 @@ struct TagArgs {
   int* argmax;
   float* maxprob;
   const bf16_t* hid; long ldh; long lead; int P, T, d;
+  const bf16_t* hid_lo;
   const float* w2;
   const float* b2;
   float* offsets;
@@ -59,7 +61,7 @@ struct TagArgs {
 };
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
 int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s, int split,
-                           int shift);
+                           int shift, bf16_t* x_lo = nullptr);
 
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s);
 
@@ -110,7 +112,7 @@ struct ZeroMulti {
 };
 int wfl_launch_zero_halo_multi(const ZeroMulti& z, hipStream_t s);
 int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s, int split,
-                           int shift);
+                           int shift, const bf16_t* x_lo = nullptr);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -193,6 +195,7 @@ struct wfl_model {
   int mel_maxw = 0;
   Lin conv1, conv2;
   bf16_t* pos = nullptr;
+  bf16_t* pos_lo = nullptr;     // precision high: what the table's bf16 rounding left behind
   std::vector<EncLayer> enc;
   LNp enc_ln;
   // wavlm
@@ -711,6 +714,15 @@ static int finalize_whisper(wfl_model* m, Packer& P) {
     std::vector<uint16_t> pb(pe->data.size());
     for (size_t i = 0; i < pb.size(); ++i) pb[i] = f32_to_bf16_bits(pe->data[i]);
     m->pos = (bf16_t*)P.upload(pb);
+    if (a.precision) {
+      for (size_t i = 0; i < pb.size(); ++i) {
+        const uint32_t u = (uint32_t)pb[i] << 16;
+        float xh;
+        memcpy(&xh, &u, 4);
+        pb[i] = f32_to_bf16_bits(pe->data[i] - xh);
+      }
+      m->pos_lo = (bf16_t*)P.upload(pb);
+    }
   }
   const float qs = (float)(std::pow((double)hd, -0.5) * 1.4426950408889634);   // hd^-1/2 * log2(e)
   m->enc.resize(a.enc_layers);
@@ -1186,7 +1198,9 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   if (a.precision) {
     p.lo_delta = round_up(off, 256);
     off = 2 * p.lo_delta;                                // the twin
-    const long rows = std::max(p.R2, p.R), cols = std::max<long>(std::max<long>(3L * std::max(p.d, p.da), 2L * p.ffw), 1024);
+    long rows = std::max(p.R2, p.R);
+    for (int i = 1; i < p.nlev; ++i) rows = std::max(rows, p.Rl[i]);                       // (WavLM: the feature encoder's levels are GEMM outputs too)
+    const long cols = std::max<long>(std::max<long>(3L * std::max(p.d, p.da), 2L * p.ffw), 1024);
     p.hp32_floats = rows * cols;
     p.hp32 = take(p.hp32_floats * 4);
   }
@@ -1393,6 +1407,7 @@ struct Runner {
     f.n_out = glu ? W.n_valid / 2 : W.n_valid;
     f.bias = W.bias; f.clip_bias = clip_bias; f.clip_idx = clip_idx; f.clip_ld = clip_ld;
     f.act = act; f.alpha = alpha; f.pos = pos; f.ldpos = ldpos;
+    f.pos_lo = (pos && pos == m->pos) ? m->pos_lo : nullptr;
     f.res = res; f.res_lo = res ? lo_in(res) : nullptr; f.ldres = ldres;
     f.out = (bf16_t*)C; f.out_lo = lo_of(C); f.ldc = ldc; f.c_lead = c_lead; f.c_pitch = c_pitch;
     f.clip_T = clip_T_for(P);
@@ -1481,6 +1496,8 @@ struct Runner {
     }
     const int w = padded ? p.da : p.d;
     bf16_t* qk = buf(padded ? p.QKp : p.QK);
+    if (precise() && !o8 && std::getenv("WFL_SPLIT_ATTN") == nullptr)
+      if (const bf16_t* ql = lo_in(qk)) { a.QK_lo = ql; a.V_lo = ql + 2 * w; }     // q | k | v as hi + lo (their projection's finish kernel wrote both)
     a.QK = qk; a.ldqk = 3 * w; a.lead = p.lead; a.V = qk + 2 * w; a.ldv = 3 * w; a.O = buf(padded ? p.ATTp : p.ATT); a.ldo = w;
     a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = w;
     a.clip_T = clipT;
@@ -1704,6 +1721,11 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     R.prof_end(2042, 0.0);
     if (r) return fail(r, "mel launch failed");
     R.lo_ok[1] = false;
+    if (R.precise()) {                                 // the fp32 mel power once more, as hi + lo rows
+      const int r2 = wfl_launch_f32_to_rows(la.raw, Y, d, p.lead, B, p.P, p.T, a.n_mels, R.s, m->pad_split(), m->pad_shift(), R.lo_of(Y));
+      if (r2) return fail(r2, "f32_to_rows launch failed");
+      R.lo_ok[1] = true;
+    }
   } else {
     // ---- WavLM (HF modeling_wavlm.py:1032-1088).  The reference never pads WavLM input: with `lens` every clip keeps its own sample
     // and frame counts through the whole forward (Runner::clipT), i.e. what it gets when it is labelled alone.
@@ -1838,7 +1860,8 @@ static int emit_hidden(Runner& R, float* hidden) {
   const Plan& p = R.p;
   if (m->a.encoder_type == WFL_ENC_NONE)           // the mel power itself, before its rounding into the bf16 rows
     return wfl_launch_axpy(hidden, (const float*)(R.ws + p.raw), (long)p.B * p.T * m->a.n_mels, 1.f, 1, R.s);
-  return wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, p.B, p.P, p.T, m->dv, hidden, R.s, m->pad_split(), m->pad_shift());
+  return wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, p.B, p.P, p.T, m->dv, hidden, R.s, m->pad_split(), m->pad_shift(),
+                                R.lo_in(R.buf(p.Y)));
 }
 
 // Head (model.py:176-194) + tag decision on the encoder output in the Y rows.
@@ -1957,7 +1980,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
     TagArgs t{};
     t.rows = B * p.T; t.C = a.num_classes; t.threshold = threshold; t.o_id = a.o_id;
     t.ids = ids; t.argmax = argmax; t.maxprob = maxprob;
-    t.hid = S; t.ldh = d; t.lead = p.lead; t.P = p.P; t.T = p.T; t.d = d; t.w2 = m->off_w2; t.b2 = m->off_b2;
+    t.hid = S; t.hid_lo = R.lo_in(S); t.ldh = d; t.lead = p.lead; t.P = p.P; t.T = p.T; t.d = d; t.w2 = m->off_w2; t.b2 = m->off_b2;
     t.clip_T = R.clipT; t.Tmax = p.T;
     if (n_pass == 1) {
       t.logits = lg; t.ldl = a.num_classes; t.offsets = offsets;
@@ -2056,8 +2079,10 @@ int32_t wfl_head(wfl_model* m, const float* hidden, int32_t B, int32_t T, const 
   const Plan& p = R.p;
   if (!workspace || workspace_bytes < p.total) return fail(-1, "wfl_head: workspace too small");
   if (int r = begin_forward(R, false)) return r;
-  const int r = wfl_launch_f32_to_rows(hidden, R.buf(p.Y), p.d, p.lead, B, p.P, p.T, m->dv, R.s, m->pad_split(), m->pad_shift());
+  const int r = wfl_launch_f32_to_rows(hidden, R.buf(p.Y), p.d, p.lead, B, p.P, p.T, m->dv, R.s, m->pad_split(), m->pad_shift(),
+                                       R.precise() ? R.lo_of(R.buf(p.Y)) : nullptr);
   if (r) return fail(r, "f32_to_rows launch failed");
+  if (R.precise()) R.lo_ok[1] = true;
   return run_head(R, lang_id, lang_mode, threshold, ids, argmax, maxprob, offsets, logits, status);
 }
 

@@ -261,43 +261,48 @@ int wfl_launch_zero_halo(bf16_t* buf, long ld_bytes, long lead, int B, int P, in
 // (split, shift): compact channel c lives in row column c + (c >= split ? shift : 0) -- the padded head layout of model.hip's
 // pad_head_state; split = C, shift = 0 for every other model
 __global__ __launch_bounds__(256) void rows_to_f32_kernel(const bf16_t* __restrict__ x, long ldx, long lead, int B, int P, int T,
-                                                          int C, float* __restrict__ out, int split, int shift) {
+                                                          int C, float* __restrict__ out, int split, int shift,
+                                                          const bf16_t* __restrict__ x_lo) {
   const long total = (long)B * T * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long bt = i / C;
     const int t = (int)(bt % T), b = (int)(bt / T);
-    out[i] = bf2f(x[(lead + (long)b * P + t) * ldx + c + (c >= split ? shift : 0)]);
+    const long o = (lead + (long)b * P + t) * ldx + c + (c >= split ? shift : 0);
+    out[i] = x_lo ? bf2f(x[o]) + bf2f(x_lo[o]) : bf2f(x[o]);              // (precision high: hi + lo)
   }
 }
 
 int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s, int split,
-                           int shift) {
+                           int shift, const bf16_t* x_lo) {
   const long total = (long)B * T * C;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rows_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, C, out, split, shift);
+  hipLaunchKernelGGL(rows_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, C, out, split, shift, x_lo);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // compact fp32 [B][T][C] -> bf16 frame rows (wfl_head: the caller's encoder output)
 __global__ __launch_bounds__(256) void f32_to_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ x, long ldx, long lead,
-                                                          int B, int P, int T, int C, int split, int shift) {
+                                                          int B, int P, int T, int C, int split, int shift, bf16_t* __restrict__ x_lo) {
   const long total = (long)B * T * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long bt = i / C;
     const int t = (int)(bt % T), b = (int)(bt / T);
-    x[(lead + (long)b * P + t) * ldx + c + (c >= split ? shift : 0)] = f2bf(in[i]);
+    const long o = (lead + (long)b * P + t) * ldx + c + (c >= split ? shift : 0);
+    const bf16_t h = f2bf(in[i]);
+    x[o] = h;
+    if (x_lo) x_lo[o] = f2bf(in[i] - bf2f(h));              // (precision high: the value's low half)
   }
 }
 
 int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s, int split,
-                           int shift) {
+                           int shift, bf16_t* x_lo) {
   const long total = (long)B * T * C;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(f32_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, x, ldx, lead, B, P, T, C, split, shift);
+  hipLaunchKernelGGL(f32_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, x, ldx, lead, B, P, T, C, split, shift, x_lo);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -21,6 +21,7 @@ struct PreciseFinishArgs {
   const float* clip_bias; const int* clip_idx; int clip_ld;
   int act; float alpha;
   const bf16_t* pos; long ldpos;          // [T][ldpos] added after the activation, or null
+  const bf16_t* pos_lo;                   //   and the table's low half (same layout), or null
   const bf16_t* res; const bf16_t* res_lo; long ldres;     // residual rows (same row mapping as the output) or null
   bf16_t* out; bf16_t* out_lo; long ldc; long c_lead; int c_pitch;
   const int* clip_T;                      // ragged batches: rows t >= clip_T[b] are not stored
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void precise_finish_kernel(PreciseFinishArgs p
       else if (p.act == WFL_ACT_RELU) x = fmaxf(x, 0.f);
       else if (p.act == WFL_ACT_SIGMOID) x = sigmoidf_(x);
       if (p.pos) x += bf2f(p.pos[(long)t * p.ldpos + n0 + e]);
+      if (p.pos_lo) x += bf2f(p.pos_lo[(long)t * p.ldpos + n0 + e]);
       v[e] = x;
     }
     const long orow = p.c_lead + (long)b * p.c_pitch + t;
