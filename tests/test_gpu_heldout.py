@@ -34,7 +34,8 @@ def _segments(ids, offsets, labels):
 
 
 @pytest.mark.parametrize("target,head,n_clips", [("fp32_weights", "cfg2", N_CLIPS), ("bf16_weights", "cfg2", N_CLIPS),
-                                                 ("bf16_weights", "default_head", 8), ("fp32_weights_precision_high", "cfg2", N_CLIPS)])
+                                                 ("bf16_weights", "default_head", 8), ("fp32_weights_precision_high", "cfg2", N_CLIPS),
+                                                 ("fp32_weights_precision_high", "default_head", 8)])
 def test_held_out_set_tag_index_parity(target, head, n_clips, tmp_path):
     """head = cfg2: BASELINE configs[1] (Whisper-base + 2 Conformer), all 64 clips.  head = default_head: the reference's default
     config.yaml head (2-layer BiLSTM + 2 Conformer + 2 dilated convs) on the first 8 clips of the same set -- the oracle's BiLSTM is

@@ -27,46 +27,65 @@ def _build(cfg, n_phonemes, seed):
     return m, labels, sd_np
 
 
-def test_precision_high_on_the_cfg2_golden(golden_dir):
-    """The reference's own outputs on the checkpoint as given (tests/golden/whisper_base_cfg2.npz): the default build is within
-    0.151 / 0.034 of its logits with 30 of 3000 raw argmax decisions different; precision high within 0.0004 / 0.00007 with none
-    (GEMMs and attention over bf16 pairs, the positional table, the offset head's input and the emitted hidden states as hi + lo)."""
-    name = "whisper_base_cfg2"
+# per golden: (hidden max, hidden mean, logits max, logits mean, max-prob, offsets, raw argmax mismatches allowed)
+_GOLDEN_BOUNDS = {
+    "whisper_base_cfg2": (5e-4, 5e-5, 2e-3, 4e-4, 5e-4, 2e-4, 1),       # measured 7e-5 / 9e-6, 3.6e-4 / 7e-5, 8e-5, 2e-5, 0 of 3000
+    "whisper_base_full": (5e-4, 5e-5, 4e-3, 8e-4, 1e-3, 4e-4, 2),       # the default config.yaml head: BiLSTM (split-precision recurrence)
+    "wavlm_base_cfg1": (2e-3, 2e-4, 2e-3, 4e-4, 5e-4, 4e-4, 0),
+    "whisper_tiny": (5e-4, 5e-5, 4e-3, 8e-4, 1e-3, 4e-4, 0),
+    "wavlm_tiny_group": (2e-3, 2e-4, 4e-3, 8e-4, 1e-3, 4e-4, 0),
+    "wavlm_tiny_stable": (2e-3, 2e-4, 4e-3, 8e-4, 1e-3, 4e-4, 0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_GOLDEN_BOUNDS))
+def test_precision_high_on_the_reference_goldens(name, golden_dir):
+    """The reference's own outputs on the checkpoint as given (tests/golden/*.npz).  cfg2: the default build is within 0.151 / 0.034 of
+    its logits with 30 of 3000 raw argmax decisions different; precision high within 0.0004 / 0.00007 with none (GEMMs and attention
+    over bf16 pairs, the positional table, the offset head's input and the emitted hidden states as hi + lo).  The other goldens: the
+    default config.yaml head behind Whisper-base (BiLSTM: split-precision recurrence), WavLM-base, and the tiny models of each family."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = GOLDEN_CASES[name]()
     cfg["model"]["precision"] = "high"
     m, labels, _ = _build(cfg, int(g["n_phonemes"]), int(g["seed"]))
     B, L = len(g["lang_id"]), int(g["L"])
-    wav = synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
+    # (the WavLM-base golden was generated on the reference's own smoke-test input, a 1 s sine: tests/golden/make_golden.py)
+    wav = np.stack([synth.sine_clip(L)] * B) if name == "wavlm_base_cfg1" else synth.make_batch(int(g["clip0"]), B, L, seed=int(g["seed"]))
     out = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True, want_hidden=True)
     m.check(B, L)
-    r = g["rows"]
-    hid_err = np.abs(out.hidden.cpu().numpy()[:, r] - g["hidden_rows"])
-    lg_err = np.abs(out.logits.cpu().numpy()[:, r] - g["logits_rows"])
+    if "rows" in g.files:
+        r = g["rows"]
+        hid_err = np.abs(out.hidden.cpu().numpy()[:, r] - g["hidden_rows"])
+        lg_err = np.abs(out.logits.cpu().numpy()[:, r] - g["logits_rows"])
+    else:
+        hid_err = np.abs(out.hidden.cpu().numpy() - g["hidden"])
+        lg_err = np.abs(out.logits.cpu().numpy() - g["logits"])
     of_err = np.abs(out.offsets.cpu().numpy() - g["offsets"])
     mp_err = np.abs(out.maxprob.cpu().numpy() - g["maxprob"])
     raw = int((out.argmax.cpu().numpy() != g["argmax"]).sum())
-    tau = 0.04
+    tau = 0.005
     bad = int((out.argmax.cpu().numpy() != g["argmax"])[g["margin"] > tau].sum())
     _note("golden_precision_high_" + name, hidden_max=hid_err.max(), hidden_mean=hid_err.mean(), logits_max=lg_err.max(), logits_mean=lg_err.mean(),
           maxprob_max=mp_err.max(), offsets_max=of_err.max(), tau=tau, safe_frac=(g["margin"] > tau).mean(), argmax_bad=bad,
           argmax_all_mismatch=raw, frames=int(g["argmax"].size))
-    assert hid_err.max() <= 5e-4 and hid_err.mean() <= 5e-5
-    assert lg_err.max() <= 2e-3 and lg_err.mean() <= 4e-4
-    assert mp_err.max() <= 5e-4 and of_err.max() <= 2e-4
-    assert bad == 0 and raw <= 1 and (g["margin"] > tau).mean() >= 0.95
+    hm, hmean, lm, lmean, mpb, ofb, rawb = _GOLDEN_BOUNDS[name]
+    assert hid_err.max() <= hm and hid_err.mean() <= hmean
+    assert lg_err.max() <= lm and lg_err.mean() <= lmean
+    assert mp_err.max() <= mpb and of_err.max() <= ofb
+    assert bad == 0 and raw <= rawb and (g["margin"] > tau).mean() >= 0.97
     again = m.label(torch.from_numpy(wav).cuda(), g["lang_id"], threshold=0.5, want_logits=True)
     assert torch.equal(again.logits, out.logits)                               # deterministic
-    one = m.label(torch.from_numpy(wav[1:2]).cuda(), g["lang_id"][1:2], threshold=0.5, want_logits=True)
-    assert torch.equal(one.logits[0], out.logits[1])                            # a clip labelled alone = the clip inside the batch
+    if B > 1:
+        one = m.label(torch.from_numpy(wav[1:2]).cuda(), g["lang_id"][1:2], threshold=0.5, want_logits=True)
+        assert torch.equal(one.logits[0], out.logits[1])                        # a clip labelled alone = the clip inside the batch
 
 
 @pytest.mark.parametrize("kind", ["whisper_default_head", "wavlm_group", "wavlm_stable_ragged", "none"])
 def test_precision_high_across_model_families(kind):
     """Tiny models of every family against the oracle: the default `config.yaml` head (BiLSTM + Conformer with GLU and the k = 31
     convolution + dilated stack) behind Whisper, both WavLM topologies (one of them as a ragged batch), and `encoder_type: none` with
-    its zero-padded head width.  Precision high must be at least as close to the oracle as the default build's tolerances, and closer
-    than the default build itself where nothing stays bf16 by design (Whisper without a BiLSTM is covered by the golden test)."""
+    its zero-padded head width.  Nothing stays bf16 in this mode -- the BiLSTM recurrence, the feature extractor, the positional
+    conv, the gated relative-position attention included -- so every family must land within 1e-3 of the oracle's logits."""
     lens = None
     if kind == "whisper_default_head":
         cfg = tiny_whisper_config()
@@ -109,6 +128,8 @@ def test_precision_high_across_model_families(kind):
         errs[prec] = (float(e.max()), float(e.mean()))
     _note("precision_high_family_" + kind, logit_std=std, default_max=errs["default"][0], default_mean=errs["default"][1], high_max=errs["high"][0],
           high_mean=errs["high"][1])
-    # never worse than the default build's own bounds (0.40 / 0.07 at the cfg2 fixture's logit std of 6.5)
-    assert errs["high"][0] <= 0.40 * max(1.0, std / 6.5) and errs["high"][1] <= 0.07 * max(1.0, std / 6.5)
-    assert errs["high"][1] <= errs["default"][1] * (1.0 if kind == "whisper_default_head" else 0.6) + 1e-6, errs
+    # measured: 0.0004 / 0.00008 for the three encoder families (default build: 0.13-0.19 / 0.03-0.045), 0.001 / 0.00013 for
+    # `encoder_type: none` (its hidden states are mel POWERS up to 3 000: 16 significant bits of those; default 0.88 / 0.08)
+    k = max(1.0, std / 6.5)
+    assert errs["high"][0] <= 0.004 * k and errs["high"][1] <= 0.0008 * k, errs
+    assert errs["high"][1] <= errs["default"][1] * 0.05, errs

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #define KT 64          // keys per tile
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 // V tile rows are HD*2 + 32 bytes apart: the 8 key rows x 32 bytes one 32-lane half of a ds_read_b64_tr_b16 touches then
 // fall into 8 different 32-byte windows of the 256-byte bank row (conflict-free for HD = 32 .. 640).
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -45,7 +46,7 @@ static __device__ __forceinline__ int k_swz(int row) {
 // and the context are three MFMA passes each (the products of two low halves are dropped: 2^-18 relative).  A tile holds four images.
 template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
-  static_assert(!SPLIT || (!BIAS && !OUT8), "split precision: the plain kernels");
+  static_assert(!SPLIT || !OUT8, "split precision: bf16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VPITCH = HD * 2 + 32;
   constexpr int TILE1 = KT * HD * 2 + KT * VPITCH;          // K tile [KT][HD] (16-byte chunks XOR-swizzled) + V tile [KT][VPITCH]
@@ -236,7 +237,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int r = kk * 16 + c;
+#if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 3       // (diagnostic: no fragment reads from LDS; results are wrong)
+        const bf16x8 kf = qf[0][ks];
+#else
         const bf16x8 kf = *(const bf16x8*)(Ks + r * (HD * 2) + (((ks * 4 + g) ^ k_swz<HD>(r)) << 4));
+#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           st[qt][kk] = attn_mfma(kf, qf[qt][ks], st[qt][kk]);
@@ -280,10 +285,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float m = st[qt][0][0];
+#if !(defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 5)  // (diagnostic: no running maximum; results are wrong)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
           for (int e = 0; e < 4; ++e) m = fmaxf(m, st[qt][kk][e]);
+#endif
         mx[qt] = m;
         over = over || m > RESCALE_THR;
       }
@@ -318,6 +325,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 1     // (diagnostic build of tools/micro/conv0_probe.hip: no transcendental instructions)
           t[e] = f2bf(st[qt][2 * s2][e] * 0.001f);
           t[4 + e] = f2bf(st[qt][2 * s2 + 1][e] * 0.001f);
+#elif defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 8   // (diagnostic: no softmax arithmetic at all -- no exp2, no conversion)
+          t[e] = __builtin_bit_cast(bf16x2_t, st[qt][2 * s2][e])[1];
+          t[4 + e] = __builtin_bit_cast(bf16x2_t, st[qt][2 * s2 + 1][e])[1];
 #else
           t[e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2][e]));
           t[4 + e] = f2bf(__builtin_amdgcn_exp2f(st[qt][2 * s2 + 1][e]));
@@ -346,12 +356,21 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const char* vp = Vs + (32 * s2 + 4 * g + (c >> 2)) * VPITCH + (dt * 16 + 4 * (c & 3)) * 2;
+#if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 3
+        const bf16x8 vf = qf[0][s2];
+        (void)vp;
+#else
         const bf16x4 lo = ds_read_tr(vp);
         const bf16x4 hi = ds_read_tr(vp + 16 * VPITCH);
         const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#endif
+#if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 7       // (diagnostic: the V fragments are read, the context MFMAs are not issued)
+        asm volatile("" :: "v"(vf));
+#else
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           o[qt][dt] = attn_mfma(vf, pf[qt][s2], o[qt][dt]);
+#endif
         if (SPLIT) {
           const bf16x4 llo = ds_read_tr(vp + TILE1);
           const bf16x4 lhi = ds_read_tr(vp + TILE1 + 16 * VPITCH);
@@ -369,10 +388,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       // barrier; then start tile kt+2's loads
       Ks = smem + ((kt + 1) & 1) * TILE_BYTES;
       Vs = Ks + KT * HD * 2;
+#if !(defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 4)  // (diagnostic: the first tile over and over; results are wrong)
       store_tile();
       if (kt + 2 < ntiles) load_tile(kt + 2);
+#endif
       stage_bias(kt + 1);
+#if !(defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 6)  // (diagnostic: no barrier -- racy, results are wrong)
       __syncthreads();
+#endif
     }
   }
 
@@ -449,9 +472,13 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.bias || hd != 64 || a.ldo8 % 4) return -4;
     return launch_attn<64, 2, true, false, true>(a, s);
   }
-  if (a.QK_lo && a.V_lo && !a.bias && !a.O8) {          // "model.precision: high": three passes over split operands
-    if (hd == 64) return launch_attn<64, 2, true, false, false, true>(a, s);
-    if (hd == 256) return launch_attn<256, 1, false, false, false, true>(a, s);
+  if (a.QK_lo && a.V_lo && !a.O8) {                     // "model.precision: high": three passes over split operands
+    if (a.bias && a.gate && hd == 64) return launch_attn<64, 2, true, true, false, true>(a, s);     // (WavLM-base / -large)
+    if (a.bias && a.gate && hd == 32) return launch_attn<32, 2, true, true, false, true>(a, s);
+    if (!a.bias && hd == 32) return launch_attn<32, 2, true, false, false, true>(a, s);
+    if (!a.bias && hd == 64) return launch_attn<64, 2, true, false, false, true>(a, s);
+    if (!a.bias && hd == 128) return launch_attn<128, 2, true, false, false, true>(a, s);
+    if (!a.bias && hd == 256) return launch_attn<256, 1, false, false, false, true>(a, s);
   }
   if (a.bias) {
     if (!a.gate) return -1;

@@ -114,10 +114,12 @@ struct AttnArgs {
 struct LstmArgs {
   const float* gx; long ldgx;      // frame rows, fp32: col = dir*4H + 4*unit + gate
   const bf16_t* whh;               // [2][G][4U][H] bf16, slice rows = 4*u_local + gate
+  const bf16_t* whh_lo;            // "model.precision: high": W_hh - bf16(W_hh), same layout; with out_lo it selects the split-precision
+  bf16_t* out_lo;                  //   recurrence (h carried and exchanged as a bf16 pair, three MFMA passes; H <= 256) -- else null
   bf16_t* out; long ldo;           // frame rows: col = dir*H + unit
   long lead;
   int B, T, P, H, U, G;
-  unsigned long long* hx;          // exchange granules: [2 dir][groups][2 parity][H/8 blocks of 8 units][16 clips][4]
+  unsigned long long* hx;          // exchange granules: [2 dir][groups][2 halves: hi, lo][2 parity][H/8 blocks of 8 units][16 clips][4]
   unsigned* error;                 // the forward's error word (ORed into)
   int grp0;                        // first clip group of this launch
   int ngroups;                     // clip groups of the whole batch (exchange indexing)

@@ -75,12 +75,16 @@ typedef __attribute__((address_space(3))) void* lstm_lptr_t;
 // RAG: clips of different lengths (LstmArgs::clip_T).  Its own instantiation, because a per-lane frame index turns the scalar row
 // arithmetic of the loader wave and of the output store into 64-bit vector arithmetic on the step's critical path: with clips of one
 // length (every Whisper batch) that cost 3.85 against 3.25 ms per 16-clip forward (A/B on one box, default head).
-template <int H, int MAXT, bool RAG>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
+// SPLIT ("model.precision: high", LstmArgs::whh_lo / out_lo): W_hh and h as bf16 pairs hi + lo -- the low halves of W_hh in registers
+// beside the high ones, h_t published as two granules (a second image behind the first), gates += W_hi h_hi + W_lo h_hi + W_hi h_lo.
+template <int H, int MAXT, bool RAG, bool SPLIT = false>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   static_assert(MAXT % 2 == 0, "tiles are paired");
+  static_assert(!SPLIT || H <= 256, "split precision: both halves of the W_hh slice stay in registers");
   constexpr int KS = H / 32;                     // K steps of 32 hidden units
   constexpr int NP = MAXT / 2;                   // tile pairs per wave
   __shared__ bf16x8 hfrag[2][KS][64];            // h_{t-1} as MFMA B fragments: [parity][K step][lane]
+  __shared__ bf16x8 hfrag_lo[SPLIT ? 2 : 1][SPLIT ? KS : 1][64];
   // gx ring: [slot][compute wave][tile][lane] float4 = the (i, f, g, o) pre-activations a lane starts a step from, brought in by the
   // loader wave's LDS-DMA (dynamic shared memory: LSTM_NR x 4 x MAXT KiB)
   extern __shared__ __attribute__((aligned(16))) char lstm_dyn[];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
 
   // ---- W_hh fragments -> registers (once).  MFMA A row a = lane & 15 of tile (pair pp, parity e) is gate a & 3 of unit
   // 8 pp + 2 (a >> 2) + e; the lane supplies k = 32 ks + 8 g .. + 8.
-  bf16x8 w[MAXT][KS];
+  bf16x8 w[MAXT][KS], w_lo[SPLIT ? MAXT : 1][SPLIT ? KS : 1];
 #pragma unroll
   for (int i = 0; i < MAXT && wid < 4; ++i) {
     // (a wave whose pair index is beyond the slice -- only with the narrow slices of the test hook -- runs the same code on
@@ -121,14 +125,19 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
       // Opaque to the compiler from here on: an invariant global load is "rematerialisable", and hipcc then re-loads all
       // 32 KiB of a wave's fragments from L2 in every step (measured: 2.1 us per step) instead of keeping them in registers.
       asm volatile("" : "+v"(w[i][ks]));
+      if (SPLIT) {
+        w_lo[i][ks] = *(const bf16x8*)(p.whh_lo + (wsrc - p.whh) + ks * 32);
+        asm volatile("" : "+v"(w_lo[i][ks]));
+      }
     }
   }
 
   const int clip = grp * 16 + c;
   const int clip_rd = clip < p.B ? clip : p.B - 1;
   const long gran_per_img = 16L * (H / 2);                                    // granules per parity image
-  unsigned long long* hx = p.hx + ((long)(dir * p.ngroups + grp) * 2) * gran_per_img;
-  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)(2 * gran_per_img * 8), 0x00020000);
+  unsigned long long* hx = p.hx + ((long)(dir * p.ngroups + grp) * 4) * gran_per_img;     // [hi, lo][2 parity] images of this team
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)(4 * gran_per_img * 8), 0x00020000);
+  constexpr unsigned LO_IMG = (unsigned)(2 * 16L * (H / 2) * 8);                            // byte offset of the low halves' images
 
   float cstate[MAXT];
 #pragma unroll
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   auto step = [&](int s) __attribute__((always_inline)) {
     const int t = dir == 0 ? s : Tc - 1 - s;               // (per lane: the clip's own frame, LstmArgs::clip_T)
     f32x4 acc[MAXT];
-    bf16x8 hf[KS];
+    bf16x8 hf[KS], hfl[SPLIT ? KS : 1];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) acc[i] = gxl[(((s & (LSTM_NR - 1)) * 4 + wid) * MAXT + i) * 64 + lane];
     LSTAMP(0);
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
         // Two poll attempts in flight, issued half a round trip apart (a failed attempt costs a whole ~0.6 us round trip; the
         // loads return in issue order, so attempt n + 1 is already on its way when attempt n is examined).
         u32x4 ga0[NK], gb0[NK], ga1[NK], gb1[NK];
+        u32x4 la0[SPLIT ? NK : 1], lb0[SPLIT ? NK : 1];      // SPLIT: the low halves' granules (the single-attempt poll only)
         auto issue = [&](u32x4* ga, u32x4* gb) __attribute__((always_inline)) {
 #pragma unroll
           for (int j = 0; j < NK; ++j) {
@@ -241,6 +251,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
               const unsigned off = (unsigned)((((par * (H / 8) + 4 * ks + g) * 16) + c) * 32);
               ga[j] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off, 0, LSTM_SC1);
               gb[j] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off + 16, 0, LSTM_SC1);
+              if (SPLIT) {
+                la0[j] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off + LO_IMG, 0, LSTM_SC1);
+                lb0[j] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, off + LO_IMG + 16, 0, LSTM_SC1);
+              }
             }
           }
         };
@@ -250,6 +264,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
           for (int j = 0; j < NK; ++j) {
             const int ks = wid + 4 * j;
             if (ks < KS) ok = ok && ga[j][1] == want && ga[j][3] == want && gb[j][1] == want && gb[j][3] == want;
+            if (SPLIT && ks < KS) ok = ok && la0[j][1] == want && la0[j][3] == want && lb0[j][1] == want && lb0[j][3] == want;
           }
 #ifdef WFL_LSTM_NOWAIT
           return true;
@@ -265,6 +280,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
               bf16x8 hv;
               __builtin_memcpy(&hv, &d, 16);
               hfrag[par][ks][lane] = hv;
+              if (SPLIT) {
+                u32x4 dl = {la0[j][0], la0[j][2], lb0[j][0], lb0[j][2]};
+                bf16x8 hl;
+                __builtin_memcpy(&hl, &dl, 16);
+                hfrag_lo[par][ks][lane] = hl;
+              }
             }
           }
         };
@@ -302,9 +323,17 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
       // pair (vector pipe) can run beside the next pair's MFMAs (matrix pipe)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) hf[ks] = hfrag[par][ks][lane];
+      if (SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) hfl[ks] = hfrag_lo[par][ks][lane];
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) hf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // h_{-1} = 0
+      if (SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) hfl[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
     }
 #ifdef WFL_LSTM_KMAJOR
 #pragma unroll
@@ -321,19 +350,27 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks) {
           acc[2 * ip + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * ip + e][ks], hf[ks], acc[2 * ip + e], 0, 0, 0);
+          if (SPLIT) {
+            acc[2 * ip + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[2 * ip + e][ks], hf[ks], acc[2 * ip + e], 0, 0, 0);
+            acc[2 * ip + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2 * ip + e][ks], hfl[ks], acc[2 * ip + e], 0, 0, 0);
+          }
+        }
 #endif
-      bf16_t hb[2];
+      bf16_t hb[2], hbl[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int i = 2 * ip + e;
         const float ig = sigm(acc[i][0]), fg = sigm(acc[i][1]), gg = tanh_(acc[i][2]), og = sigm(acc[i][3]);
         cstate[i] = fg * cstate[i] + ig * gg;
-        hb[e] = f2bf(og * tanh_(cstate[i]));
+        const float hv = og * tanh_(cstate[i]);
+        hb[e] = f2bf(hv);
+        hbl[e] = f2bf(hv - bf2f(hb[e]));
       }
-      unsigned bits;
+      unsigned bits, bits_lo = 0;
       __builtin_memcpy(&bits, hb, 4);
+      if (SPLIT) __builtin_memcpy(&bits_lo, hbl, 4);
       const int u0 = slice * U + 8 * pp + 2 * g;                   // first of this lane's two consecutive units
       if (pp < npair) {
         if (s + 1 < p.T) {                                         // publish: one granule, write-through
@@ -341,9 +378,17 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
           const u32x2 gr = {bits, (unsigned)(s + 1)};
           if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, 0);        // stays in the team's L2
           else __builtin_amdgcn_raw_buffer_store_b64(gr, hx_rsrc, off, 0, LSTM_SC1);          // write-through: any placement
+          if (SPLIT) {
+            const u32x2 gl = {bits_lo, (unsigned)(s + 1)};
+            if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(gl, hx_rsrc, off + LO_IMG, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(gl, hx_rsrc, off + LO_IMG, 0, LSTM_SC1);
+          }
         }
 #ifndef WFL_LSTM_NO_OUT       // (diagnostic builds: tools/micro/lstm_bench.hip)
-        if (clip < p.B && (!RAG || s < Tc)) *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
+        if (clip < p.B && (!RAG || s < Tc)) {
+          *(unsigned*)(p.out + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits;
+          if (SPLIT) *(unsigned*)(p.out_lo + (p.lead + (long)clip * p.P + t) * p.ldo + dir * H + u0) = bits_lo;
+        }
 #endif
       }
     }
@@ -353,11 +398,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   for (int s = 0; s < p.T; ++s) step(s);
 }
 
-template <int H, int MAXT, bool RAG>
+template <int H, int MAXT, bool RAG, bool SPLIT = false>
 static int launch_lstm_r(const LstmArgs& a, int groups, hipStream_t s) {
   const int teams = 2 * groups;
   constexpr int lds = LSTM_NR * 4 * MAXT * 1024;       // the gx ring (dynamic; the fragment images are static shared memory)
-  auto k = lstm_kernel<H, MAXT, RAG>;
+  auto k = lstm_kernel<H, MAXT, RAG, SPLIT>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
@@ -372,8 +417,14 @@ static int launch_lstm_r(const LstmArgs& a, int groups, hipStream_t s) {
 
 template <int H, int MAXT>
 static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
+  if constexpr (H <= 256) {
+    if (a.whh_lo && a.out_lo)
+      return a.clip_T ? launch_lstm_r<H, MAXT, true, true>(a, groups, s) : launch_lstm_r<H, MAXT, false, true>(a, groups, s);
+  }
   return a.clip_T ? launch_lstm_r<H, MAXT, true>(a, groups, s) : launch_lstm_r<H, MAXT, false>(a, groups, s);
 }
+
+bool wfl_lstm_split_precision_supported(int H) { return H <= 256; }
 
 // Units per WG: 32 (four waves x one pair of 16-row tiles) when it divides H, else the largest multiple of 8 below that does.
 // Measured at H = 256, 16 clips (tools/micro/lstm_bench.hip): 64 units per WG (4 WGs per direction) 2.14 us per step, 32 units
@@ -392,8 +443,9 @@ int wfl_lstm_units_per_wg(int H) {
 
 long wfl_lstm_exchange_bytes(int H, int B) {
   const long groups = (B + 15) / 16;
-  // granule images [2 dir][groups][2 parity][H/8][16][4] x 8 bytes, then the roll-call granules [2 dir][groups][64] x 8 bytes
-  return 2 * groups * 2 * 16 * (long)(H / 2) * 8 + 2 * groups * 64 * 8 + 64;
+  // granule images [2 dir][groups][2 halves][2 parity][H/8][16][4] x 8 bytes (the low halves' images: precision high only), then the
+  // roll-call granules [2 dir][groups][64] x 8 bytes
+  return 2 * groups * 4 * 16 * (long)(H / 2) * 8 + 2 * groups * 64 * 8 + 64;
 }
 
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
@@ -403,10 +455,10 @@ int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s) {
   const int groups = (a.B + 15) / 16;
   if (2 * a.G > 128) return -5;
   a.hx = (unsigned long long*)exchange;
-  a.roll = a.hx + 2L * groups * 2 * 16 * (a.H / 2);
+  a.roll = a.hx + 2L * groups * 4 * 16 * (a.H / 2);
   a.ngroups = groups;
   // tags of an earlier launch must not validate: clear the granule images and the roll call (a kernel, not a memset node: common.h)
-  if (wfl_launch_fill_i32((int*)exchange, 2L * groups * 2 * 16 * (a.H / 2) * 2 + 2L * groups * 64 * 2, 0, s)) return -3;
+  if (wfl_launch_fill_i32((int*)exchange, 2L * groups * 4 * 16 * (a.H / 2) * 2 + 2L * groups * 64 * 2, 0, s)) return -3;
   // Residency contract.  A team (the G workgroups of one direction of one group of 16 clips) makes progress only while ALL its
   // workgroups are resident -- one per CU, ~133 KiB of LDS each -- and launches are plain, so nothing checks that.  Two rules keep a
   // team from ever waiting on a CU that another waiting team holds:

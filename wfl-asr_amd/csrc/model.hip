@@ -76,6 +76,7 @@ struct Conv0Args {
   double* cstats;
   float* cpart;
   bf16_t* out; long lead; int P;
+  bf16_t* out_lo;
 };
 int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s, const int* lens = nullptr);
 int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s);
@@ -90,13 +91,14 @@ int wfl_launch_posconv(const PosConvArgs& a, hipStream_t s);
 int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s,
                        const int* clip_T = nullptr);
 int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
-                           const float* b8, const float* cst, float* gate, hipStream_t s);
+                           const float* b8, const float* cst, float* gate, hipStream_t s, const bf16_t* x_lo = nullptr);
 int wfl_launch_relpos_table(const float* rel_emb, const int* bucket_of_delta, int max_t, int heads, int T, float* table, hipStream_t s);
 int wfl_launch_layernorm_act(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps, long lead,
                              int B, int P, int T, int C, int gelu, hipStream_t s, const bf16_t* x_lo = nullptr, bf16_t* y_lo = nullptr,
                              int n_div = 0, const int* clip_T = nullptr);
 int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
+bool wfl_lstm_split_precision_supported(int H);
 int wfl_launch_rows_fp8(const bf16_t* x, long ldx, const bf16_t* x_lo, const float* g, const float* b, float eps, long lead, int B, int P,
                         int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s);          // norm.hip
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
@@ -215,6 +217,7 @@ struct wfl_model {
   float* lang_table = nullptr;    // [num_languages][d]
   std::vector<Lin> lstm_in;       // per layer: both directions' input projection, rows [dir][unit][gate]
   std::vector<bf16_t*> lstm_whh;  // per layer: [2][G][4U][H]
+  std::vector<bf16_t*> lstm_whh_lo;   // precision high: the same slices' low halves (null entries where the recurrence stays bf16)
   int lstm_U = 0;
   std::vector<ConfLayer> conf;
   std::vector<Lin> dil;
@@ -904,7 +907,7 @@ static int finalize_head(wfl_model* m, Packer& P) {
     for (int layer = 0; layer < a.bilstm_layers && P.err.empty(); ++layer) {
       const int din = d;      // layer 0: encoder width d; deeper layers: 2H = d
       std::vector<float> rows((size_t)8 * H * din), bias((size_t)8 * H);
-      std::vector<uint16_t> whh((size_t)2 * 4 * H * H);
+      std::vector<uint16_t> whh((size_t)2 * 4 * H * H), whh_lo((size_t)2 * 4 * H * H);
       for (int dir = 0; dir < 2; ++dir) {
         const std::string suf = "_l" + std::to_string(layer) + (dir ? "_reverse" : "");
         const HostTensor* wih = P.get("bilstm.weight_ih" + suf, {4 * H, din});
@@ -921,12 +924,21 @@ static int finalize_head(wfl_model* m, Packer& P) {
             // slice-major packing: [dir][slice][4*u_local + gate][H]
             const int sl = u / U, ul = u % U;
             const size_t wrow = ((size_t)(dir * G + sl) * 4 * U) + 4 * ul + gate;
-            for (int k = 0; k < H; ++k) whh[wrow * H + k] = f32_to_bf16_bits(whh_t->data[(size_t)src * H + k]);
+            for (int k = 0; k < H; ++k) {
+              const float x = whh_t->data[(size_t)src * H + k];
+              const uint16_t hb = f32_to_bf16_bits(x);
+              const uint32_t u32 = (uint32_t)hb << 16;
+              float xh;
+              memcpy(&xh, &u32, 4);
+              whh[wrow * H + k] = hb;
+              whh_lo[wrow * H + k] = f32_to_bf16_bits(x - xh);
+            }
           }
       }
       if (!P.err.empty()) break;
       m->lstm_in.push_back(P.pack(rows, 8 * H, din, &bias));
       m->lstm_whh.push_back((bf16_t*)P.upload(whh));
+      m->lstm_whh_lo.push_back((a.precision && wfl_lstm_split_precision_supported(H)) ? (bf16_t*)P.upload(whh_lo) : nullptr);
     }
   }
   m->conf.resize(a.n_conformer);
@@ -1247,16 +1259,20 @@ struct Runner {
   // Residual stream hi + lo (common.h, GemmArgs::res_lo): X and Y have low halves; lo_ok says whether the low half of the
   // tensor currently held in X / Y is valid (a kernel that writes only the high half invalidates it).
   // "model.precision: high" (precise.hip): EVERY activation buffer has a low half, lo_delta bytes further on, and lo_ok tracks the
-  // buffers whose producer wrote it (X, Y, ATT, QK, FF, mel, c1, enc2, QKp, ATTp: indices 0 .. 9; any pointer inside the buffer counts)
+  // buffers whose producer wrote it (X, Y, ATT, QK, FF, mel, c1, enc2, QKp, ATTp, and WavLM's FA, FB, XG: indices 0 .. 12; any pointer
+  // inside the buffer counts)
   bool precise() const { return m->a.precision != 0 && p.lo_delta > 0; }
-  bool lo_ok[10] = {false, false, false, false, false, false, false, false, false, false};
+  bool lo_ok[13] = {false, false, false, false, false, false, false, false, false, false, false, false, false};
   int lo_idx(const void* ptr) const {               // default mode -- 0: inside X's first row (a column offset is allowed), 1: Y, else -1
     if (precise()) {
       const long o = (const char*)ptr - ws;
-      const long st[10] = {p.X, p.Y, p.ATT, p.QK, p.FF, p.mel, p.c1, p.enc2, p.QKp, p.ATTp};
-      const long sz[10] = {p.R * p.d * 2, p.R * p.d * 2, p.R * p.d * 2, p.R * 3L * p.d * 2, p.R * (long)p.ffw * 2, p.mel > 0 || m->a.encoder_type == WFL_ENC_WHISPER ? p.R2 * m->a.n_mels * 2 + 1024 : 0,
-                           m->a.encoder_type == WFL_ENC_WHISPER ? p.R2 * (long)p.d * 2 : 0, p.R * p.d * 2, p.da != p.d ? p.R * 3L * p.da * 2 : 0, p.da != p.d ? p.R * (long)p.da * 2 : 0};
-      for (int i = 0; i < 10; ++i)
+      const bool wavlm = m->a.encoder_type == WFL_ENC_WAVLM;
+      const long C0 = wavlm ? m->a.wavlm_conv_dim[0] : 0;
+      const long st[13] = {p.X, p.Y, p.ATT, p.QK, p.FF, p.mel, p.c1, p.enc2, p.QKp, p.ATTp, p.FA, p.FB, p.XG};
+      const long sz[13] = {p.R * p.d * 2, p.R * p.d * 2, p.R * p.d * 2, p.R * 3L * p.d * 2, p.R * (long)p.ffw * 2, p.mel > 0 || m->a.encoder_type == WFL_ENC_WHISPER ? p.R2 * m->a.n_mels * 2 + 1024 : 0,
+                           m->a.encoder_type == WFL_ENC_WHISPER ? p.R2 * (long)p.d * 2 : 0, p.R * p.d * 2, p.da != p.d ? p.R * 3L * p.da * 2 : 0, p.da != p.d ? p.R * (long)p.da * 2 : 0,
+                           wavlm ? p.Rl[0] * C0 * 2 : 0, wavlm ? p.Rl[1] * C0 * 2 : 0, wavlm ? (long)m->a.wavlm_pos_conv_groups * p.R * 64 * 2 : 0};
+      for (int i = 0; i < 13; ++i)
         if (sz[i] > 0 && o >= st[i] && o < st[i] + sz[i]) return i;
       return -1;
     }
@@ -1298,6 +1314,24 @@ struct Runner {
       gemm_precise(A, lda, W, M, P, T, C, ldc, c_lead, c_pitch, act, res, ldres, alpha, cin, tap_stride, glu, pos, ldpos, clip_bias, clip_idx,
                    clip_ld);
       return;
+    }
+    if (precise() && out_f32 && !next_acc_f32 && act == WFL_ACT_NONE && W.W_lo && !W.w8 && !glu && !res && !pos && !clip_bias && !W.ln_s) {
+      // fp32 output (the BiLSTM's input projection): the two correction passes first -- A_hi W_lo^T, then A_lo W_hi^T added to it, no
+      // bias -- and the plain launch below adds A_hi W_hi^T + b to them
+      const bf16_t* A_lo = lo_in(A);
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !A_lo) break;
+        GemmArgs g{};
+        g.A = pass == 1 ? A_lo : A; g.lda = lda;
+        g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
+        g.W = pass == 0 ? W.W_lo : W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.n_valid;
+        g.P = P; g.T = T; g.clip_T = clip_T_for(P);
+        g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch;
+        g.alpha = 1.f; g.act = WFL_ACT_NONE; g.out_f32 = 1; g.acc_f32 = pass;
+        const int r = wfl_launch_gemm(g, s);
+        if (r) { rc = fail(r, "gemm launch failed (precision high, fp32 output, pass " + std::to_string(pass) + ")"); return; }
+      }
+      next_acc_f32 = true;
     }
     GemmArgs g{};
     g.ln_s = W.ln_s; g.ln_eps = 1e-5f;
@@ -1748,10 +1782,13 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     }
     // Rows that are not valid frames of a level are zeroed before the level is produced (the two buffers alternate
     // between levels; a K-padded conv GEMM may read a few channels past the last valid frame).
+    const long D = R.precise() ? p.lo_delta : 0;       // precision high: the feature extractor's rows as bf16 pairs too
     R.zero(p.FA, C, p.leadl[0], p.Pl[0], p.Tl[0], p.tail);
+    if (D) R.zero(p.FA + D, C, p.leadl[0], p.Pl[0], p.Tl[0], p.tail);
     if (R.rc) return R.rc;
     {
       Conv0Args c{};
+      if (D) { c.out_lo = R.lo_of(F[0]); R.lo_ok[10] = c.out_lo != nullptr; }
       c.wav = wav; c.ldw = ldw; c.L = L; c.wstats = wstats; c.w = m->conv0_w; c.bias = m->conv0_b;
       c.gamma = m->conv0_norm.g; c.beta = m->conv0_norm.b; c.B = B; c.T0 = p.Tl[0]; c.C = C; c.lens = lens;
       c.cstats = (double*)(R.ws + p.cstats); c.cpart = (float*)(R.ws + p.cpart); c.out = F[0]; c.lead = p.leadl[0]; c.P = p.Pl[0];
@@ -1764,18 +1801,19 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       bf16_t* out = F[i & 1];
       const bool group = a.wavlm_group_norm != 0;
       R.zero((i & 1) ? p.FB : p.FA, C, p.leadl[i], p.Pl[i], p.Tl[i], p.tail);
+      if (D) R.zero(((i & 1) ? p.FB : p.FA) + D, C, p.leadl[i], p.Pl[i], p.Tl[i], p.tail);
       R.gemm(in, 2 * C, m->fconv[i - 1], B * p.Pl[i], p.Pl[i], p.Tl[i], out, C, p.leadl[i], p.Pl[i], group ? WFL_ACT_GELU : WFL_ACT_NONE);
       if (!group && !R.rc) {
         const int r = wfl_launch_layernorm_act(out, C, out, C, m->fconv_ln[i - 1].g, m->fconv_ln[i - 1].b, 1e-5f, p.leadl[i], B,
-                                               p.Pl[i], p.Tl[i], C, 1, R.s, nullptr, nullptr, 0, R.levelT[i]);
+                                               p.Pl[i], p.Tl[i], C, 1, R.s, R.lo_in(out), D ? R.lo_of(out) : nullptr, 0, R.levelT[i]);
         if (r) return fail(r, "layernorm launch failed");
       }
     }
     if (R.rc) return R.rc;
     bf16_t* feats = F[(n - 1) & 1];                    // level n-1 has the main geometry (lead, P, T)
     {
-      const int r = wfl_launch_layernorm_act(feats, C, feats, C, m->fp_ln.g, m->fp_ln.b, 1e-5f, p.lead, B, p.P, p.T, C, 0, R.s, nullptr, nullptr,
-                                             0, R.clipT);
+      const int r = wfl_launch_layernorm_act(feats, C, feats, C, m->fp_ln.g, m->fp_ln.b, 1e-5f, p.lead, B, p.P, p.T, C, 0, R.s, R.lo_in(feats),
+                                             D ? R.lo_of(feats) : nullptr, 0, R.clipT);
       if (r) return fail(r, "layernorm launch failed");
     }
     R.next_lo_out = true;
@@ -1785,14 +1823,19 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       const int G = a.wavlm_pos_conv_groups, cpg = d / G, K = a.wavlm_pos_conv_kernel;
       bf16_t* XG = R.buf(p.XG);
       if (!R.rc) {
-        const int r = wfl_launch_regroup(X, d, G, cpg, p.R, p.lead, B, p.P, p.T, XG, R.s, R.clipT);
+        int r = wfl_launch_regroup(X, d, G, cpg, p.R, p.lead, B, p.P, p.T, XG, R.s, R.clipT);
+        R.lo_ok[12] = false;
+        if (!r && D && R.lo_in(X)) {                 // the low halves in the same layout: the per-group GEMMs' third pass
+          r = wfl_launch_regroup(R.lo_in(X), d, G, cpg, p.R, p.lead, B, p.P, p.T, R.lo_of(XG), R.s, R.clipT);
+          R.lo_ok[12] = true;
+        }
         if (r) return fail(r, "regroup launch failed");
       }
       // all groups in one tap-stationary launch (posconv.hip); WFL_POSCONV_GEMM=1 keeps rounds 1-2's GEMM per group (A/B runs)
       static int as_gemm = -1;
       if (as_gemm < 0) { const char* e = getenv("WFL_POSCONV_GEMM"); as_gemm = e && atoi(e) ? 1 : 0; }
       int taken = 1;
-      if (!as_gemm && !R.rc && G <= 16) {
+      if (!as_gemm && !D && !R.rc && G <= 16) {      // (precision high: the GEMM per group, three passes each)
         PosConvArgs pc{};
         pc.xg = XG; pc.R = p.R; pc.lead = p.lead; pc.B = B; pc.P = p.P; pc.T = p.T; pc.groups = G; pc.cpg = cpg; pc.taps = K;
         for (int gi = 0; gi < G; ++gi) { pc.w[gi] = m->posconv[gi].W; pc.bias[gi] = m->posconv[gi].bias; }
@@ -1824,7 +1867,7 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
       bf16_t* A_in = H;                                // what the attention block sees
       if (stable) { R.ln(H, S, L_.ln1); A_in = S; }
       if (R.rc) break;
-      int r = wfl_launch_relpos_gate(A_in, d, p.lead, B, p.P, p.T, a.enc_heads, hd, L_.w8, L_.b8, L_.cst, gate, R.s);
+      int r = wfl_launch_relpos_gate(A_in, d, p.lead, B, p.P, p.T, a.enc_heads, hd, L_.w8, L_.b8, L_.cst, gate, R.s, R.lo_in(A_in));
       if (r) return fail(r, "relpos_gate launch failed");
       R.gemm(A_in + (long)p.lead * d, d, L_.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P);
       R.attn(a.enc_heads, rtab, gate);
@@ -1915,7 +1958,10 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
         la.error = (unsigned*)(R.ws + p.err);
         la.clip_T = R.clipT;
         R.stats_for = nullptr;
-        { const int si = R.lo_idx(S); if (si >= 0) R.lo_ok[si] = false; }     // the recurrence writes plain bf16 rows
+        // the recurrence writes plain bf16 rows -- or, precision high with H <= 256, h as a bf16 pair like every other activation
+        const bool split = R.precise() && m->lstm_whh_lo[layer] != nullptr && R.lo_of(S) != nullptr;
+        if (split) { la.whh_lo = m->lstm_whh_lo[layer]; la.out_lo = R.lo_of(S); }
+        { const int si = R.lo_idx(S); if (si >= 0) R.lo_ok[si] = split; }
         R.prof_begin();
         const int lr = wfl_launch_lstm(la, R.ws + p.lstm_x, R.s);
         R.prof_end(2041, 2.0 * (double)B * p.T * 2.0 * 4.0 * (double)Hh * (double)Hh);

@@ -49,6 +49,7 @@ struct Conv0Args {
   double* cstats;                         // [B][C][2] (group mode)
   float* cpart;                           // [B][time blocks][C][2] per-workgroup partial sums (group mode, pass 1)
   bf16_t* out; long lead; int P;          // frame rows [.., C]
+  bf16_t* out_lo;                         // precision high: the rows' low halves (same layout) or null
 };
 
 static __device__ __forceinline__ void wav_norm(const Conv0Args& p, int b, float& mean, float& rstd) {
@@ -124,9 +125,16 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args p) {
         } else {
           typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
           bf16x2 o;
-          o[0] = f2bf(gelu_erf(fmaf(ya, sca, sha)));
-          o[1] = f2bf(gelu_erf(fmaf(yb, scb, shb)));
+          const float ga = gelu_erf(fmaf(ya, sca, sha)), gb = gelu_erf(fmaf(yb, scb, shb));
+          o[0] = f2bf(ga);
+          o[1] = f2bf(gb);
           *(bf16x2*)(op + (long)t * p.C) = o;
+          if (p.out_lo) {
+            bf16x2 ol;
+            ol[0] = f2bf(ga - bf2f(o[0]));
+            ol[1] = f2bf(gb - bf2f(o[1]));
+            *(bf16x2*)(p.out_lo + (op - p.out) + (long)t * p.C) = ol;
+          }
         }
       }
     }
@@ -198,10 +206,15 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args p) {
     for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
     const float rs = rsqrtf(sq / p.C + 1e-5f);
     if (act) {
-      bf16x8 o;
+      bf16x8 o, ol;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf((y[e] - mu) * rs * gm[e] + bt[e]));
+      for (int e = 0; e < 8; ++e) {
+        const float v = gelu_erf((y[e] - mu) * rs * gm[e] + bt[e]);
+        o[e] = f2bf(v);
+        ol[e] = f2bf(v - bf2f(o[e]));
+      }
       *(bf16x8*)(p.out + (p.lead + (long)b * p.P + t) * p.C + c0) = o;
+      if (p.out_lo) *(bf16x8*)(p.out_lo + (p.lead + (long)b * p.P + t) * p.C + c0) = ol;
     }
   }
 }
@@ -293,7 +306,7 @@ int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long
 __global__ __launch_bounds__(256) void relpos_gate_kernel(const bf16_t* __restrict__ x, long ldx, long lead, int B, int P, int T,
                                                           int heads, int hd, const float* __restrict__ w8,
                                                           const float* __restrict__ b8, const float* __restrict__ cst,
-                                                          float* __restrict__ gate) {
+                                                          float* __restrict__ gate, const bf16_t* __restrict__ x_lo) {
   const long total = (long)B * T * heads;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int h = (int)(i % heads);
@@ -311,6 +324,15 @@ __global__ __launch_bounds__(256) void relpos_gate_kernel(const bf16_t* __restri
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc[o] = fmaf(w8[o * hd + k + e], xv, acc[o]);
       }
+      if (x_lo) {                                   // (precision high: the hidden states' low halves)
+        const bf16x8 vl = *(const bf16x8*)(x_lo + (xp - x) + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = bf2f(vl[e]);
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[o] = fmaf(w8[o * hd + k + e], xv, acc[o]);
+        }
+      }
     }
     const float ga = sigmoidf_(acc[0] + acc[1] + acc[2] + acc[3]);
     const float gb = sigmoidf_(acc[4] + acc[5] + acc[6] + acc[7]);
@@ -319,12 +341,12 @@ __global__ __launch_bounds__(256) void relpos_gate_kernel(const bf16_t* __restri
 }
 
 int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
-                           const float* b8, const float* cst, float* gate, hipStream_t s) {
+                           const float* b8, const float* cst, float* gate, hipStream_t s, const bf16_t* x_lo) {
   if (hd % 8 || ldx % 8) return -1;
   const long total = (long)B * T * heads;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(relpos_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, heads, hd, w8, b8, cst, gate);
+  hipLaunchKernelGGL(relpos_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, lead, B, P, T, heads, hd, w8, b8, cst, gate, x_lo);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
