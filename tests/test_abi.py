@@ -58,6 +58,25 @@ def test_create_validates_arch_without_gpu(libpath):
     lib.wfl_destroy(h)
 
 
+def test_precision_high_sizes_the_twin_workspace_without_gpu(libpath):
+    """wfl_arch.precision (config.yaml `model.precision: high`): the activation area gets its twin for the low halves and the fp32
+    accumulator of the three-pass GEMMs -- visible in wfl_workspace_bytes before any GPU is touched."""
+    from wfl_asr_amd import _lib
+    lib = _lib.load()
+    sizes = []
+    for prec in (0, 1):
+        a = _lib.WflArch()
+        a.abi_version = _lib.ABI_VERSION
+        a.d_model, a.enc_layers, a.enc_heads, a.enc_ffn, a.n_mels, a.max_positions = 64, 1, 4, 128, 80, 100
+        a.num_classes, a.o_id = 5, 4
+        a.precision = prec
+        h = ctypes.c_void_p(0)
+        assert lib.wfl_create(ctypes.byref(a), ctypes.byref(h)) == 0 and h.value, lib.wfl_last_error()
+        sizes.append(lib.wfl_workspace_bytes(h, 2, 32000))
+        lib.wfl_destroy(h)
+    assert sizes[0] > 0 and sizes[1] > 2 * sizes[0] * 0.9, sizes
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "wfl-asr_amd")
     for dp, _, fs in os.walk(pkg):
