@@ -133,3 +133,45 @@ def test_precision_high_across_model_families(kind):
     k = max(1.0, std / 6.5)
     assert errs["high"][0] <= 0.004 * k and errs["high"][1] <= 0.0008 * k, errs
     assert errs["high"][1] <= errs["default"][1] * 0.05, errs
+
+
+def test_validation_pass_on_the_fast_path_matches_the_oracle_forward():
+    """wfl-asr_amd/validate.py:evaluate (train.py:456-545) on the HIP forward against the same metrics computed from the oracle's forward
+    (`max_label_len` pad / truncate included): precision high, so that the two argmax streams agree frame for frame."""
+    from oracle import wfl_metrics as M
+    from wfl_asr_amd import validate as V
+    from wfl_asr_amd.postprocess import decode_bio_tags, merge_adjacent_segments, median_filter_ids
+    cfg = tiny_whisper_config()
+    cfg["model"]["precision"] = "high"
+    cfg["postprocess"] = {"median_filter": 3, "merge_segments": "right"}
+    m, labels, sd_np = _build(cfg, 5, seed=71)
+    B, L = 3, 32000
+    wav = synth.make_batch(950, B, L, seed=71)
+    lang = np.array([0, 1, 0], np.int64)
+    T = 100
+    lengths = torch.tensor([100, 93, 61])
+    rng = np.random.default_rng(71)
+    label_ids = torch.from_numpy(rng.integers(0, len(labels), size=(B, T)))
+    gts = [[(0.1 * i, 0.1 * i + 0.08, labels[int(rng.integers(len(labels) - 1))][2:]) for i in range(6)] for _ in range(B)]
+    batch = (torch.from_numpy(wav), label_ids, [None] * B, gts, ["a", "b", "c"], torch.from_numpy(lang), lengths)
+    loss = V.evaluate(m, [batch], labels, cfg, criterion=torch.nn.CrossEntropyLoss())
+    got = dict(V.evaluate.last)
+    m.check(B, L)
+    enc, arch = resolve_encoder_arch(cfg["model"], cfg.get("data"))
+    sd = O.to_torch_state_dict(sd_np)
+    hc = synth.head_config(cfg["model"])
+    _, _, hid = O.forward(torch.from_numpy(wav), torch.from_numpy(lang), sd, enc, arch, hc, return_hidden=True)
+    lg, of = O.head_forward(hid[:, :T], torch.from_numpy(lang), sd, hc)
+    want_loss = float(torch.nn.CrossEntropyLoss()(lg.reshape(-1, lg.size(-1)), label_ids.reshape(-1)))
+    acc = per = ter = 0.0
+    for j in range(B):
+        n = int(lengths[j])
+        ids = median_filter_ids(lg[j, :n].argmax(-1).numpy(), 3)
+        segs = merge_adjacent_segments(decode_bio_tags([labels[int(i)] for i in ids], frame_duration=0.02, offsets=of[j, :n].numpy()), mode="right")
+        acc += M.frame_accuracy(lg[j, :n].numpy(), label_ids[j, :n].numpy())
+        per += M.edit_rate(segs, gts[j])
+        ter += M.timing_rate(segs, gts[j])
+    _note("validation_pass", loss=loss, loss_ref=want_loss, acc=got["accuracy"], acc_ref=acc / B, per=got["per"], per_ref=per / B, ter=got["ter"],
+          ter_ref=ter / B)
+    assert abs(loss - want_loss) <= 2e-4 and got["clips"] == B
+    assert abs(got["accuracy"] - acc / B) <= 1e-9 and abs(got["per"] - per / B) <= 1e-9 and abs(got["ter"] - ter / B) <= 2e-4
