@@ -359,7 +359,8 @@ def main():
             tot_fl = sum(p["flops"] for p in gemm)
             tot_n = sum(p["launches"] for p in gemm)
             top = max(gemm, key=lambda p: p["ms"])
-            traffic = pmc_traffic()
+            # (the committed PMC passes are of the default command: they describe BASELINE configs[1] in bf16 only)
+            traffic = pmc_traffic() if (args.config_index == 1 and not args.full_head and args.precision == "default") else None
             breakdown = {"bf16 MFMA GEMM family": tot_ms / args.steps}
             for p in other:
                 breakdown[OTHER_KEYS.get(p["key"], str(p["key"]))] = p["ms"] / args.steps
