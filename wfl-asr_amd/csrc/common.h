@@ -31,6 +31,9 @@ struct GemmArgs {
   long lda;             // elements
   int cin;              // channels per tap; k -> tap = k / cin, c = k % cin, at +tap * tap_stride + c
   long tap_stride;      // elements between taps (= dilation * C of the input buffer); cin >= K => single tap
+  int tap_wrap;         // > 0 ("model.precision: high", one-launch form): K holds THREE segments of tap_wrap taps each -- tap index t reads at
+  long seg_off;         //   (t % tap_wrap) * tap_stride, plus seg_off for the middle segment (the operand's low half, lo_delta away):
+                        //   [A_hi | A_lo | A_hi] against weights packed [W_hi | W_hi | W_lo]
   const bf16_t* W;      // [N][K] row-major, N % 128 == 0, K % 64 == 0 (zero padded)
   int M, N, K;
   int n_valid;          // columns >= n_valid are not stored

@@ -79,7 +79,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   auto stage = [&](int buf, int kt) {
     const int k0 = kt * BK;
     const int tap = k0 / p.cin;
-    const long koff = (long)tap * p.tap_stride + (k0 - tap * p.cin);
+    long toff = (long)tap * p.tap_stride;
+    if (p.tap_wrap > 0) {                           // three segments of tap_wrap taps (GemmArgs::tap_wrap)
+      const int sg = tap / p.tap_wrap;
+      toff = (long)(tap - sg * p.tap_wrap) * p.tap_stride + (sg == 1 ? p.seg_off : 0);
+    }
+    const long koff = toff + (k0 - tap * p.cin);
     char* base = smem + buf * STAGE_BYTES + wid * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(a_src[i] + koff, base + i * 1024);

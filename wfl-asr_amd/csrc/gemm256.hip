@@ -80,7 +80,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   auto stage = [&](int buf, int kt) {
     const int k0 = kt * BK2;
     const int tap = k0 / p.cin;
-    const long koff = (long)tap * p.tap_stride + (k0 - tap * p.cin);
+    long toff = (long)tap * p.tap_stride;
+    if (p.tap_wrap > 0) {                           // three segments of tap_wrap taps (GemmArgs::tap_wrap)
+      const int sg = tap / p.tap_wrap;
+      toff = (long)(tap - sg * p.tap_wrap) * p.tap_stride + (sg == 1 ? p.seg_off : 0);
+    }
+    const long koff = toff + (k0 - tap * p.cin);
     char* base = smem + buf * ST2;
     glds16b(a_src[0] + koff, base + xg0 * 1024);
     if (two_x) glds16b(a_src[1] + koff, base + xg0 * 1024 + 1024);

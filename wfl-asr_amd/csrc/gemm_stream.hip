@@ -134,6 +134,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   int islot = 0;                                    // ring slot of the next stage to issue (= issued % SNST)
   int ptap_k = 0;                                   // position inside the current tap (conv GEMMs), elements
   long pbase = 0;                                   // tap * tap_stride
+  int ptap_i = 0, pseg = 0;                         // GemmArgs::tap_wrap: tap inside the segment, segment
+  auto next_tap = [&]() __attribute__((always_inline)) {
+    ptap_k = 0;
+    if (p.tap_wrap > 0 && ++ptap_i == p.tap_wrap) { ptap_i = 0; ++pseg; pbase = pseg == 1 ? p.seg_off : 0; }
+    else pbase += p.tap_stride;
+  };
   int pcc = 0, ptap = 0, pccg = 0;                  // CONV: channel chunk / tap being issued; chunks issued so far (buffer parity)
   auto set_src = [&](int v) __attribute__((always_inline)) {
     int m0, n0;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     ++issued;
     ++pkt;
     ptap_k += SBK;
-    if (ptap_k == p.cin) { ptap_k = 0; pbase += p.tap_stride; }
+    if (ptap_k == p.cin) next_tap();
   };
   // Steady-state variant: the frame pieces (and the weight pieces that are not deferred) now, the NDC deferred weight pieces from
   // inside the MFMA block of the same step (issue_deferred).  An LDS-DMA instruction issued right behind a burst of ds_reads costs
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     ++issued;
     ++pkt;
     ptap_k += SBK;
-    if (ptap_k == p.cin) { ptap_k = 0; pbase += p.tap_stride; }
+    if (ptap_k == p.cin) next_tap();
   };
   auto issue_deferred = [&](int j, auto ndc_c) __attribute__((always_inline)) {     // j-th deferred weight piece (j < NDC)
     constexpr int NDC = decltype(ndc_c)::value;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     if (pv >= ntiles) return;
     issue_stage();
     if (pkt == nk) {
-      pkt = 0; ptap_k = 0; pbase = 0; pcc = 0; ptap = 0;
+      pkt = 0; ptap_k = 0; pbase = 0; pcc = 0; ptap = 0; ptap_i = 0; pseg = 0;
       pv += G;
       if (pv < ntiles) set_src(pv);
     }
@@ -666,7 +672,7 @@ static bool wfl_gemm_stream_conv(const GemmArgs& a) {
   // (at least SNST - 1 taps: a chunk's extended frame tile is issued SNST - 1 stages before its first tap and overwrites the buffer of
   //  the chunk before last, whose last tap must have been read by then)
   return a.cin < a.K && a.K % a.cin == 0 && a.K / a.cin <= 32 && a.K / a.cin >= SNST - 1 && a.tap_stride == a.lda && a.cin % SBK == 0 &&
-         !a.res && !a.ln_s && !a.stats_out;
+         !a.res && !a.ln_s && !a.stats_out && a.tap_wrap == 0;
 }
 
 // The launches this kernel takes (everything else stays with gemm256 / gemm).
@@ -678,6 +684,7 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   return false;
 #endif
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
+  if (a.tap_wrap > 0 && (a.ln_s || a.w8_scale || a.a8)) return false;
   if (a.c_lo && !a.res) return false;
   if (a.w8_scale && (a.cin < a.K || a.K % 64)) return false;
   if (a.a8 && (!a.w8_scale || a.ln_s || a.stats_out || a.stats_in || a.K % 128 || a.lda % 16 || a.K / 64 < 8 || (a.c8 && (a.res || a.ldc8 % 8))))

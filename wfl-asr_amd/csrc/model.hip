@@ -152,6 +152,7 @@ struct Lin {
   float* ln_s = nullptr; // set on a LayerNorm-folded operand: s[n] = sum_k W'[n][k] (gemm_stream.hip), bias = b + W beta
   float* w8 = nullptr;   // set on an fp8 operand: W holds OCP e4m3 bytes [N][K], w8[n] = the row's scale (GemmArgs::w8_scale)
   bf16_t* W_lo = nullptr; // "model.precision: high": bf16(w - bf16(w)), same layout as W (precise.hip)
+  bf16_t* W3 = nullptr;   //   and the one-launch form's operand [N][3 K]: rows [W_hi | W_hi | W_lo] (GemmArgs::tap_wrap)
 };
 struct LNp { float* g = nullptr; float* b = nullptr; };
 
@@ -384,6 +385,13 @@ struct Packer {
           wl[(size_t)n * L.K + k] = f32_to_bf16_bits(x - xh);
         }
       L.W_lo = (bf16_t*)upload(wl);
+      std::vector<uint16_t> w3((size_t)L.N * 3 * L.K);
+      for (int n = 0; n < L.N; ++n) {
+        memcpy(&w3[((size_t)n * 3 + 0) * L.K], &w[(size_t)n * L.K], (size_t)L.K * 2);
+        memcpy(&w3[((size_t)n * 3 + 1) * L.K], &w[(size_t)n * L.K], (size_t)L.K * 2);
+        memcpy(&w3[((size_t)n * 3 + 2) * L.K], &wl[(size_t)n * L.K], (size_t)L.K * 2);
+      }
+      L.W3 = (bf16_t*)upload(w3);
     }
     std::vector<float> b((size_t)L.N, 0.f);
     if (bias) for (int n = 0; n < n_valid; ++n) b[n] = (*bias)[n];
@@ -1402,9 +1410,50 @@ struct Runner {
     stats_in_next = false;
     if (C == stats_for) stats_for = nullptr;
     const int B = M / P;
+    const bf16_t* A_lo = lo_in(A);
+    // One launch instead of three + the finish kernel, whenever the operand has its low half and the fused epilogues can do what the
+    // layer needs: K' = 3 K with the weights packed [W_hi | W_hi | W_lo] against the taps [A_hi | A_lo | A_hi] (GemmArgs::tap_wrap; the
+    // low half of A is lo_delta away), the accumulator never leaves the registers, the epilogue writes hi AND lo.  WFL_PRECISE_FUSED=0
+    // keeps the three-launch form (A/B runs); the positional-table launch (the Whisper stem's conv2) stays there for the table's low half.
+    static int fused_on = -1;
+    if (fused_on < 0) { const char* e = getenv("WFL_PRECISE_FUSED"); fused_on = e ? atoi(e) : 1; }
+    if (fused_on && W.W3 && A_lo && !pos && lo_of(C)) {
+      GemmArgs g{};
+      g.A = A; g.lda = lda;
+      g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
+      g.tap_wrap = W.K / g.cin; g.seg_off = (long)(A_lo - A);
+      g.W = W.W3; g.M = M; g.N = W.N; g.K = 3 * W.K; g.n_valid = W.n_valid;
+      g.P = P; g.T = T; g.clip_T = clip_T_for(P);
+      g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch;
+      g.bias = W.bias; g.clip_bias = clip_bias; g.clip_idx = clip_idx; g.clip_ld = clip_ld;
+      g.res = res; g.ldres = ldres; g.alpha = alpha; g.res_lo = res ? lo_in(res) : nullptr;
+      g.act = act; g.glu = glu ? 1 : 0; g.ln_eps = 1e-5f;
+      g.c_lo = lo_of(C);
+      { const int ci = lo_idx(C); if (ci >= 0) lo_ok[ci] = true; }
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (m->prof_on) {
+        if (m->prof_used >= m->prof.ev.size()) {
+          hipEvent_t a_, b_;
+          if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) { rc = fail(-10, "hipEventCreate"); return; }
+          m->prof.ev.push_back({a_, b_});
+        }
+        e0 = m->prof.ev[m->prof_used].first; e1 = m->prof.ev[m->prof_used].second;
+        ++m->prof_used;
+        (void)hipEventRecord(e0, s);
+      }
+      const int r = wfl_launch_gemm(g, s);
+      if (m->prof_on) {
+        (void)hipEventRecord(e1, s);
+        const int key = (act & 3) | (glu ? 4 : 0) | (res ? 16 : 0) | ((g_wfl_gemm_kernel_id & 7) << 5);
+        m->prof.key.push_back(key);
+        m->prof.launches[key] += 1;
+        m->prof.flops[key] += 3.0 * 2.0 * (double)B * T * (double)W.n_valid * (double)W.K;
+      }
+      if (r) rc = fail(r, "gemm launch failed (precision high, one-launch form: " + std::to_string(r) + ")");
+      return;
+    }
     if ((long)M * W.N > p.hp32_floats) { rc = fail(-1, "precision high: the fp32 accumulator is too small for this launch"); return; }
     float* acc = (float*)(ws + p.hp32);
-    const bf16_t* A_lo = lo_in(A);
     for (int pass = 0; pass < 3; ++pass) {
       if (pass == 2 && !A_lo) break;
       GemmArgs g{};
@@ -1903,8 +1952,10 @@ static int emit_hidden(Runner& R, float* hidden) {
   const Plan& p = R.p;
   if (m->a.encoder_type == WFL_ENC_NONE)           // the mel power itself, before its rounding into the bf16 rows
     return wfl_launch_axpy(hidden, (const float*)(R.ws + p.raw), (long)p.B * p.T * m->a.n_mels, 1.f, 1, R.s);
+  // (the default build hands out the high halves only: wfl_head rounds its input to bf16 again, and bf16(hi + lo) is not always hi --
+  //  lo can round up to exactly half a unit of hi -- which would cost wfl_encode + wfl_head == wfl_forward its bit-exactness)
   return wfl_launch_rows_to_f32(R.buf(p.Y), p.d, p.lead, p.B, p.P, p.T, m->dv, hidden, R.s, m->pad_split(), m->pad_shift(),
-                                R.lo_in(R.buf(p.Y)));
+                                R.precise() ? R.lo_in(R.buf(p.Y)) : nullptr);
 }
 
 // Head (model.py:176-194) + tag decision on the encoder output in the Y rows.
