@@ -4,11 +4,13 @@
 # Counters are collected in their own runs (one --pmc set per pass, no trace domains besides the kernel trace).
 set -u
 TAG=${1:-round}
+PART=${2:-all}        # a: bench lines + kernel stats; b: counters, files -> .lab, recurrence micro-benchmarks (two gpurun calls of < 20 min)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py"
+if [ $PART != b ]; then
 echo "== bench lines"
 timeout -k 10 400 $B > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err || exit 1
 timeout -k 10 300 $B --full-head --steps 24 --warmup 3 --no-cpu-baseline > $OUT/bench_fullhead_b16.json 2>> $OUT/bench.err || exit 1
@@ -25,6 +27,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf -o fullhead_inflight1 -- $B $P --inflight 1 --full-head > $OUT/ksf.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks5 -o cfg5_inflight1 -- $B --steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --config-index 4 > $OUT/ks5.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksh -o cfg2_precision_high -- $B --steps 6 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --precision high > $OUT/ksh.log 2>&1 || exit 1
+fi
+if [ $PART = a ]; then echo done; exit 0; fi
 echo "== pmc"
 P4="--steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B $P4 > $OUT/pmc_fetch.log 2>&1 || exit 1
