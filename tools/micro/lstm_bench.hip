@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
   {   // the roll call of the last launch: which XCD every slice of every (direction, group) team ran on
     const int groups = (B + 15) / 16, G = H / a.U;
     std::vector<unsigned long long> roll((size_t)2 * groups * 64);
-    hipMemcpy(roll.data(), (unsigned long long*)ex + 2L * groups * 2 * 16 * (H / 2), roll.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(roll.data(), (unsigned long long*)ex + 2L * groups * 4 * 16 * (H / 2), roll.size() * 8, hipMemcpyDeviceToHost);
     int together = 0;
     for (int t = 0; t < 2 * groups; ++t) {
       bool same = true;
