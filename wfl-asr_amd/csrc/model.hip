@@ -1579,8 +1579,9 @@ struct Runner {
     }
     const int w = padded ? p.da : p.d;
     bf16_t* qk = buf(padded ? p.QKp : p.QK);
-    if (precise() && !o8 && std::getenv("WFL_SPLIT_ATTN") == nullptr)
-      if (const bf16_t* ql = lo_in(qk)) { a.QK_lo = ql; a.V_lo = ql + 2 * w; }     // q | k | v as hi + lo (their projection's finish kernel wrote both)
+    static const bool split_attn = std::getenv("WFL_SPLIT_ATTN") == nullptr;       // (set to anything: bf16 q, k, v, P in precision high -- A/B runs)
+    if (precise() && !o8 && split_attn)
+      if (const bf16_t* ql = lo_in(qk)) { a.QK_lo = ql; a.V_lo = ql + 2 * w; }     // q | k | v as hi + lo (their projection wrote both halves)
     a.QK = qk; a.ldqk = 3 * w; a.lead = p.lead; a.V = qk + 2 * w; a.ldv = 3 * w; a.O = buf(padded ? p.ATTp : p.ATT); a.ldo = w;
     a.B = p.B; a.T = p.T; a.P = p.P; a.heads = heads; a.d = w;
     a.clip_T = clipT;
