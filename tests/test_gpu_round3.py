@@ -80,7 +80,7 @@ def test_precision_high_on_the_reference_goldens(name, golden_dir):
         assert torch.equal(one.logits[0], out.logits[1])                        # a clip labelled alone = the clip inside the batch
 
 
-@pytest.mark.parametrize("kind", ["whisper_default_head", "wavlm_group", "wavlm_stable_ragged", "none"])
+@pytest.mark.parametrize("kind", ["whisper_default_head", "wavlm_group", "wavlm_stable_ragged", "wavlm_bilstm_ragged", "whisper_all_languages", "none"])
 def test_precision_high_across_model_families(kind):
     """Tiny models of every family against the oracle: the default `config.yaml` head (BiLSTM + Conformer with GLU and the k = 31
     convolution + dilated stack) behind Whisper, both WavLM topologies (one of them as a ragged batch), and `encoder_type: none` with
@@ -97,6 +97,13 @@ def test_precision_high_across_model_families(kind):
         cfg = tiny_wavlm_config(True, enable_bilstm=False)
         B, L = 3, 24000
         lens = np.array([24000, 15000, 9000], np.int32)
+    elif kind == "wavlm_bilstm_ragged":                     # the split-precision recurrence on clips of different lengths
+        cfg = tiny_wavlm_config(False, enable_bilstm=True)
+        B, L = 3, 24000
+        lens = np.array([21000, 24000, 8000], np.int32)
+    elif kind == "whisper_all_languages":                   # lang_id = None: the head once per listed language on one encoder output
+        cfg = tiny_whisper_config(enable_bilstm=False)
+        B, L = 2, 32000
     else:
         cfg = synth.base_config("none", enable_bilstm=False)
         B, L = 2, 16000
@@ -110,8 +117,10 @@ def test_precision_high_across_model_families(kind):
         for i in range(B):
             n = int(lens[i]) if lens is not None else L
             wav[i, :n] = synth.make_clip(900 + i, n, seed=61)
-        lang = (np.arange(B) % 2).astype(np.int64)
-        out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, lens=lens, want_logits=True)
+        lang = None if kind == "whisper_all_languages" else (np.arange(B) % 2).astype(np.int64)
+        if lang is None:
+            m.set_average_languages(list(range(cfg["model"]["num_languages"])))
+        out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, lens=lens, want_logits=True, average_languages=lang is None)
         m.check(B, L)
         outs[prec] = out.logits.cpu()
     enc, arch = resolve_encoder_arch(cfg["model"], cfg.get("data"))
@@ -121,7 +130,12 @@ def test_precision_high_across_model_families(kind):
     refs = []
     for i in range(B):
         n = int(lens[i]) if lens is not None else L
-        refs.append(O.forward(torch.from_numpy(wav[i:i + 1, :n]), torch.from_numpy(lang[i:i + 1]), sd, enc, arch, hc)[0][0])
+        if lang is None:                                     # infer.py:147-156: the mean of the logits over the language ids
+            n_lang = cfg["model"]["num_languages"]
+            refs.append(torch.stack([O.forward(torch.from_numpy(wav[i:i + 1, :n]), torch.tensor([k]), sd, enc, arch, hc)[0][0]
+                                     for k in range(n_lang)]).mean(0))
+        else:
+            refs.append(O.forward(torch.from_numpy(wav[i:i + 1, :n]), torch.from_numpy(lang[i:i + 1]), sd, enc, arch, hc)[0][0])
     std = float(torch.cat([r.reshape(-1) for r in refs]).std())
     for prec in outs:
         e = torch.cat([(outs[prec][i, :refs[i].shape[0]] - refs[i]).abs().reshape(-1) for i in range(B)])

@@ -1976,6 +1976,12 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
   if (n_pass > 1) {
     if (wfl_launch_copy16(R.buf(p.enc2), Y, p.R * d * 2, R.s)) return fail(-3, "copy launch failed");
     ENC = R.buf(p.enc2);
+    if (R.precise()) {                                   // ... and its low half
+      const bool have_lo = R.lo_in(Y) != nullptr && R.lo_of(ENC) != nullptr;
+      if (have_lo && wfl_launch_copy16(R.lo_of(ENC), R.lo_of(Y), p.R * d * 2, R.s)) return fail(-3, "copy launch failed");
+      const int ei = R.lo_idx(ENC);
+      if (ei >= 0) R.lo_ok[ei] = have_lo;
+    }
   }
   int* lang_dev = nullptr;
   for (int pass = 0; pass < n_pass; ++pass) {
