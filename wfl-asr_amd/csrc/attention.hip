@@ -34,6 +34,24 @@ static __device__ __forceinline__ f32x4 attn_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 #define attn_mfma(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
 
+#ifndef WFL_ATTN_DMA
+#define WFL_ATTN_DMA 1     // the prefetching kernels (head_dim 32 / 64 / 128) stage K and V tiles with LDS-DMA: no staging registers (158 -> 139
+#endif                     // VGPRs at head_dim 64), no ds_write, no wait between a tile's loads and its stores.  Round 3, tools/attn_bench.py:
+                           // 97.5 -> 89.6 us at cfg2 size, 550 -> 493 us at cfg5 size, bit-identical output.  0: the register-staged form of rounds 1-2
+typedef __attribute__((address_space(1))) const void* attn_gptr_t;
+typedef __attribute__((address_space(3))) void* attn_lptr_t;
+// DMA layout of the V tile: rows HD * 2 bytes apart (an LDS-DMA instruction writes 1 KiB contiguously: no padding), the 32-byte windows
+// (one output-channel tile each) of a row XORed so that the 8 key rows x 32 bytes one half of a ds_read_b64_tr_b16 touches fall into 8
+// different windows of the 256-byte bank row
+template <int HD>
+static __host__ __device__ constexpr bool attn_dma(bool prefetch) {
+  return WFL_ATTN_DMA && ((prefetch && (HD == 32 || HD == 64 || HD == 128)) || (!prefetch && HD == 256));
+}
+template <int HD>
+static __device__ __forceinline__ int v_swz(int row) {
+  return HD == 32 ? (row >> 2) & 1 : HD == 64 ? (row >> 1) & 3 : row & 7;      // (head_dim 256: a row is two bank rows; the low three window bits)
+}
+
 template <int HD>
 static __device__ __forceinline__ int k_swz(int row) {
   constexpr int CPR = HD / 8;                 // 16-byte chunks per K row
@@ -45,10 +63,12 @@ static __device__ __forceinline__ int k_swz(int row) {
 // SPLIT ("model.precision: high", AttnArgs::QK_lo / V_lo): q, k, v arrive as bf16 pairs hi + lo and P is split in registers; the scores
 // and the context are three MFMA passes each (the products of two low halves are dropped: 2^-18 relative).  A tile holds four images.
 template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
+// (Asking for four waves per SIMD -- __launch_bounds__(256, 4): 128 registers, 7 spilled -- measured slower: 99 us against 90.)
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   static_assert(!SPLIT || !OUT8, "split precision: bf16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int VPITCH = HD * 2 + 32;
+  constexpr bool DMA = attn_dma<HD>(PREFETCH);
+  constexpr int VPITCH = DMA ? HD * 2 : HD * 2 + 32;
   constexpr int TILE1 = KT * HD * 2 + KT * VPITCH;          // K tile [KT][HD] (16-byte chunks XOR-swizzled) + V tile [KT][VPITCH]
   constexpr int TILE_BYTES = SPLIT ? 2 * TILE1 : TILE1;     // SPLIT: the low halves' images behind the high ones
   // PREFETCH variants keep TWO tiles in LDS: tile kt+1 is written (from the registers its global loads landed in) right
@@ -60,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   constexpr int KS = HD / 32;            // k-steps over head_dim
   constexpr int DT = HD / 16;            // output channel tiles
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   // XCD-aware order: blocks i and i+8 share an XCD (and its L2).  All query blocks of one (clip, head) read the
   // same K / V^T, so give each XCD a contiguous run of logical blocks ordered (clip, head, query block): K/V are
@@ -183,6 +203,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
   };
 
+  // DMA staging: a wave's instruction j covers 1 KiB of the tile image (rows of HD * 2 bytes); lane l fetches the 16-byte chunk that
+  // belongs at its LDS position under the K / V swizzles
+  constexpr int NDI = DMA ? KT * HD * 2 / 1024 / 4 : 1;   // instructions per wave and image
+  int kdoff[NDI], vdoff[NDI];
+  if (DMA) {
+#pragma unroll
+    for (int j = 0; j < NDI; ++j) {
+      const int byte = (wid * NDI + j) * 1024 + lane * 16;
+      const int r = byte / (HD * 2), pos = (byte % (HD * 2)) >> 4;
+      kdoff[j] = r * (int)p.ldqk + ((pos ^ k_swz<HD>(r)) << 3);
+      vdoff[j] = r * (int)p.ldv + (((((pos >> 1) ^ v_swz<HD>(r)) << 1) | (pos & 1)) << 3);
+    }
+  }
+  auto dma_tile = [&](int kt, int buf) {
+    const bf16_t* kb = Kg + (row0 + (long)kt * KT) * p.ldqk;
+    const bf16_t* vb = Vg + (row0 + (long)kt * KT) * p.ldv;
+    char* dst = smem + buf * TILE_BYTES + wid * NDI * 1024;
+#pragma unroll
+    for (int j = 0; j < NDI; ++j) {
+      __builtin_amdgcn_global_load_lds((attn_gptr_t)(kb + kdoff[j]), (attn_lptr_t)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((attn_gptr_t)(vb + vdoff[j]), (attn_lptr_t)(dst + KT * HD * 2 + j * 1024), 16, 0, 0);
+    }
+    if (SPLIT) {
+      const bf16_t* kl = Kgl + (row0 + (long)kt * KT) * p.ldqk;
+      const bf16_t* vl = Vgl + (row0 + (long)kt * KT) * p.ldv;
+#pragma unroll
+      for (int j = 0; j < NDI; ++j) {
+        __builtin_amdgcn_global_load_lds((attn_gptr_t)(kl + kdoff[j]), (attn_lptr_t)(dst + TILE1 + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((attn_gptr_t)(vl + vdoff[j]), (attn_lptr_t)(dst + TILE1 + KT * HD * 2 + j * 1024), 16, 0, 0);
+      }
+    }
+  };
+
   // BIAS: the slice of the relative-position table a key tile needs -- offsets key - query for this workgroup's 4 * QT * 16 queries
   // and the tile's 64 keys, 64 + 4 * QT * 16 - 1 entries -- is staged in LDS one tile ahead (it rides on the tile's barrier); round 1
   // gathered every score's entry from global memory inside the loop (the BIAS kernel ran at half the plain kernel's rate)
@@ -208,18 +261,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
     stage_bias(0);
   }
-  if (PREFETCH) {
+  if (DMA && PREFETCH) {
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if (PREFETCH) {
     load_tile(0);
     store_tile();                        // tile 0 -> buffer 0
     if (ntiles > 1) load_tile(1);        // in flight under tile 0's MFMAs
     __syncthreads();
   }
   for (int kt = 0; kt < ntiles; ++kt) {
+    if (DMA && PREFETCH && kt + 1 < ntiles) dma_tile(kt + 1, (kt + 1) & 1);     // into the buffer every wave left before the last barrier
     if (!PREFETCH) {
       __syncthreads();                   // every wave is done reading the previous tile
-      load_tile(kt);
-      store_tile();
-      if (SPLIT) load_store_lo(kt);
+      if (DMA) {                         // (one buffer: the co-resident workgroup covers the wait)
+        dma_tile(kt, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        load_tile(kt);
+        store_tile();
+        if (SPLIT) load_store_lo(kt);
+      }
       __syncthreads();
     } else {
       Ks = smem + (kt & 1) * TILE_BYTES;
@@ -355,7 +418,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const char* vp = Vs + (32 * s2 + 4 * g + (c >> 2)) * VPITCH + (dt * 16 + 4 * (c & 3)) * 2;
+        const int vr = 32 * s2 + 4 * g + (c >> 2);        // (row vr + 16 has the same window swizzle)
+        const char* vp = Vs + vr * VPITCH + ((DMA ? dt ^ v_swz<HD>(vr) : dt) * 16 + 4 * (c & 3)) * 2;
 #if defined(WFL_ABL_ATTN) && WFL_ABL_ATTN == 3
         const bf16x8 vf = qf[0][s2];
         (void)vp;
@@ -383,7 +447,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         }
       }
     }
-    if (PREFETCH && kt + 1 < ntiles) {
+    if (DMA && PREFETCH && kt + 1 < ntiles) {
+      stage_bias(kt + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt + 1 has landed (this wave's pieces; the barrier covers the others')
+      __syncthreads();
+    } else if (PREFETCH && kt + 1 < ntiles) {
       // tile kt+1 (in registers since the previous iteration) -> the other buffer, which every wave left before the last
       // barrier; then start tile kt+2's loads
       Ks = smem + ((kt + 1) & 1) * TILE_BYTES;
@@ -444,7 +512,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
 static int launch_attn(const AttnArgs& a, hipStream_t s) {
   static_assert(!BIAS || PREFETCH, "the bias table slice is staged on the prefetch barrier");
-  constexpr int lds = (PREFETCH ? 2 : 1) * (SPLIT ? 2 : 1) * (KT * HD * 2 + KT * (HD * 2 + 32)) + (BIAS ? 2 * (KT + 4 * QT * 16) * 4 : 0);
+  constexpr int lds = (PREFETCH ? 2 : 1) * (SPLIT ? 2 : 1) * (KT * HD * 2 + KT * (attn_dma<HD>(PREFETCH) ? HD * 2 : HD * 2 + 32)) +
+                      (BIAS ? 2 * (KT + 4 * QT * 16) * 4 : 0);
   auto k = attn_kernel<HD, QT, PREFETCH, BIAS, OUT8, SPLIT>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
