@@ -336,42 +336,75 @@ __global__ __launch_bounds__(256) void relpos_gate_kernel(const bf16_t* __restri
                                                           int heads, int hd, const float* __restrict__ w8,
                                                           const float* __restrict__ b8, const float* __restrict__ cst,
                                                           float* __restrict__ gate, const bf16_t* __restrict__ x_lo) {
+  // the 8 x hd projection every thread applies: staged in LDS once per workgroup (it used to be re-read from global memory, 8 hd
+  // uniform loads per thread), transposed to [k][8] so that one k costs two broadcast ds_read_b128
+  __shared__ __attribute__((aligned(16))) float sw[128 * 8];
+  for (int i = threadIdx.x; i < 8 * hd; i += 256) sw[(i % hd) * 8 + i / hd] = w8[i];
+  __syncthreads();
+  // NP positions (b, t, head) per thread.  55.6 us per call at 64 x 499 frames x 16 heads with the projection read from global memory,
+  // 48.7 from LDS; NP = 4 (one pair of broadcast reads serving four frames) measured 76-80 us: too few waves left to hide the loads
+  constexpr int NP = 1;
   const long total = (long)B * T * heads;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int h = (int)(i % heads);
-    const long bt = i / heads;
-    const int t = (int)(bt % T), b = (int)(bt / T);
-    const bf16_t* xp = x + (lead + (long)b * P + t) * ldx + h * hd;
-    float acc[8];
+  const long S = (long)gridDim.x * 256;             // positions i0, i0 + S, ...: neighbouring lanes read neighbouring head slices
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += S * NP) {
+    const bf16_t* xp[NP];
+    long go[NP];
+    int hh[NP];
+    float acc[NP][8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = b8[o];
+    for (int q = 0; q < NP; ++q) {
+      const long i = i0 + q * S < total ? i0 + q * S : total - 1;  // (spare positions behind the end: computed, not stored)
+      const int h = (int)(i % heads);
+      const long bt = i / heads;
+      const int t = (int)(bt % T), b = (int)(bt / T);
+      xp[q] = x + (lead + (long)b * P + t) * ldx + h * hd;
+      go[q] = ((long)b * heads + h) * T + t;
+      hh[q] = h;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) acc[q][o] = b8[o];
+    }
     for (int k = 0; k < hd; k += 8) {
-      const bf16x8 v = *(const bf16x8*)(xp + k);
+      bf16x8 v[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) v[q] = *(const bf16x8*)(xp[q] + k);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xv = bf2f(v[e]);
+        const f32x4 wa = *(const f32x4*)(sw + (k + e) * 8), wb = *(const f32x4*)(sw + (k + e) * 8 + 4);
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = fmaf(w8[o * hd + k + e], xv, acc[o]);
+        for (int q = 0; q < NP; ++q) {
+          const float xv = bf2f(v[q][e]);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) { acc[q][o] = fmaf(wa[o], xv, acc[q][o]); acc[q][4 + o] = fmaf(wb[o], xv, acc[q][4 + o]); }
+        }
       }
       if (x_lo) {                                   // (precision high: the hidden states' low halves)
-        const bf16x8 vl = *(const bf16x8*)(x_lo + (xp - x) + k);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) v[q] = *(const bf16x8*)(x_lo + (xp[q] - x) + k);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xv = bf2f(vl[e]);
+          const f32x4 wa = *(const f32x4*)(sw + (k + e) * 8), wb = *(const f32x4*)(sw + (k + e) * 8 + 4);
 #pragma unroll
-          for (int o = 0; o < 8; ++o) acc[o] = fmaf(w8[o * hd + k + e], xv, acc[o]);
+          for (int q = 0; q < NP; ++q) {
+            const float xv = bf2f(v[q][e]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { acc[q][o] = fmaf(wa[o], xv, acc[q][o]); acc[q][4 + o] = fmaf(wb[o], xv, acc[q][4 + o]); }
+          }
         }
       }
     }
-    const float ga = sigmoidf_(acc[0] + acc[1] + acc[2] + acc[3]);
-    const float gb = sigmoidf_(acc[4] + acc[5] + acc[6] + acc[7]);
-    gate[((long)b * heads + h) * T + t] = ga * (gb * cst[h] - 1.0f) + 2.0f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if (i0 + q * S >= total) break;
+      const float ga = sigmoidf_(acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3]);
+      const float gb = sigmoidf_(acc[q][4] + acc[q][5] + acc[q][6] + acc[q][7]);
+      gate[go[q]] = ga * (gb * cst[hh[q]] - 1.0f) + 2.0f;
+    }
   }
 }
 
 int wfl_launch_relpos_gate(const bf16_t* x, long ldx, long lead, int B, int P, int T, int heads, int hd, const float* w8,
                            const float* b8, const float* cst, float* gate, hipStream_t s, const bf16_t* x_lo) {
-  if (hd % 8 || ldx % 8) return -1;
+  if (hd % 8 || ldx % 8 || hd > 128) return -1;
   const long total = (long)B * T * heads;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
