@@ -63,7 +63,8 @@ static __device__ __forceinline__ int k_swz(int row) {
 // SPLIT ("model.precision: high", AttnArgs::QK_lo / V_lo): q, k, v arrive as bf16 pairs hi + lo and P is split in registers; the scores
 // and the context are three MFMA passes each (the products of two low halves are dropped: 2^-18 relative).  A tile holds four images.
 template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
-// (Asking for four waves per SIMD -- __launch_bounds__(256, 4): 128 registers, 7 spilled -- measured slower: 99 us against 90.)
+// (Four waves per SIMD instead of three -- __launch_bounds__(256, 4) -- measured slower twice: 99 us against 90 at 139 registers / 7
+//  spilled, 93 against 91 at 129 registers / 5 spilled: a fourth workgroup per CU adds more LDS and L2 contention than latency hiding.)
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   static_assert(!SPLIT || !OUT8, "split precision: bf16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,10 +131,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   // Row sums come from the matrix pipe: one extra V^T "channel" that is all ones (a constant A fragment, lane c == 0),
   // accumulated like an output tile (osum[qt][0] of lanes g == 0), over the same bf16-rounded P as the numerator.
   constexpr float RESCALE_THR = 8.0f;
-  f32x4 o[QT][DT], osum[QT], negm[QT];
+  f32x4 o[QT][DT], osum[QT];
+  float negm[QT];                        // minus the reference of query tile qt (one value per lane's query: the accumulators start from it)
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    negm[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    negm[qt] = 0.f;
     osum[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) st[qt][kk] = negm[qt];
+      for (int kk = 0; kk < 4; ++kk) st[qt][kk] = (f32x4){negm[qt], negm[qt], negm[qt], negm[qt]};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -370,8 +372,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int e = 0; e < 4; ++e) st[qt][kk][e] -= d;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) negm[qt][e] -= d;
+          negm[qt] -= d;
           osum[qt] *= alpha;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
