@@ -64,7 +64,10 @@ static __device__ __forceinline__ int k_swz(int row) {
 // and the context are three MFMA passes each (the products of two low halves are dropped: 2^-18 relative).  A tile holds four images.
 template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLIT = false>
 // (Four waves per SIMD instead of three -- __launch_bounds__(256, 4) -- measured slower twice: 99 us against 90 at 139 registers / 7
-//  spilled, 93 against 91 at 129 registers / 5 spilled: a fourth workgroup per CU adds more LDS and L2 contention than latency hiding.)
+//  spilled, 93 against 91 at 129 registers / 5 spilled: a fourth workgroup per CU adds more LDS and L2 contention than latency hiding.
+//  A software-pipelined loop -- the scores of tile kt + 1 issued before the softmax of tile kt, K staged one tile ahead of V -- was built
+//  and removed again: hipcc wants 218 registers for it (two waves per SIMD: 106.5 us against 94.0 on the same box), and capped at
+//  three waves per SIMD it spills 66-86 of them.)
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   static_assert(!SPLIT || !OUT8, "split precision: bf16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
