@@ -72,9 +72,11 @@ typedef struct wfl_arch {
                                         fp32 scale per output channel (BASELINE configs[4]); 0: bf16 */
   int32_t mel_hop;                   /* WFL_ENC_NONE: hop of the mel front-end = int(frame_duration * sample_rate) (model.py:88);
                                         d_model = n_mels = the hidden width (model.py:91); 160 and 320 are built */
-  int32_t precision;                 /* 0: bf16 operands (default).  1 ("model.precision: high", round 3): every GEMM runs as three bf16 MFMA
-                                        passes over split operands -- A_hi W_hi + A_hi W_lo + A_lo W_hi, summed in fp32 -- with every
-                                        activation carried as a bf16 pair hi + lo: the reference's tag indices at ~3x the GEMM cost */
+  int32_t precision;                 /* 0: bf16 operands (default).  1 ("model.precision: high", round 3): every GEMM, the attention's two
+                                        products and the BiLSTM recurrence (hidden size <= 256 per direction) run as three bf16 MFMA passes
+                                        over split operands -- A_hi W_hi + A_hi W_lo + A_lo W_hi, summed in fp32 -- with every activation
+                                        carried as a bf16 pair hi + lo: the reference's tag indices at ~2.7x the forward time; the
+                                        workspace doubles (wfl_workspace_bytes) */
   int32_t reserved[7];
 } wfl_arch;
 
