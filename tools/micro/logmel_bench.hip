@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <vector>
 
+__global__ void bench_fill_kernel(int* dst, long n, int v) { for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) dst[i] = v; }
+int wfl_launch_fill_i32(int* dst, long n, int value, hipStream_t s) { hipLaunchKernelGGL(bench_fill_kernel, dim3(64), dim3(256), 0, s, dst, n, value); return 0; }
+
 int main() {
   const int B = 16, L = 480000, nfr = 3000, nm = 80;
   std::vector<float> wav((size_t)B * L);
@@ -30,15 +33,15 @@ int main() {
   LogmelArgs a{};
   a.wav = dw; a.ldw = L; a.lens = nullptr; a.L = L; a.B = B; a.n_samples = L; a.n_frames = nfr; a.n_mels = nm;
   a.Wc = dwc; a.Ws = dws; a.mel_lo = dlo; a.mel_cnt = dcnt; a.mel_w = dmw; a.mel_maxw = maxw; a.raw = raw; a.clipmax = cm; a.stamps = nullptr;
-  for (int i = 0; i < 3; ++i) wfl_launch_logmel(a, out, nm, 8, 3040, nullptr, 0);
+  for (int i = 0; i < 3; ++i) wfl_launch_logmel(a, out, nm, 8, 3040, nullptr, 0, nullptr);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  for (int i = 0; i < 10; ++i) wfl_launch_logmel(a, out, nm, 8, 3040, nullptr, 0);
+  for (int i = 0; i < 10; ++i) wfl_launch_logmel(a, out, nm, 8, 3040, nullptr, 0, nullptr);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   a.stamps = st;
-  wfl_launch_logmel(a, out, nm, 8, 3040, nullptr, 0);
+  wfl_launch_logmel(a, out, nm, 8, 3040, nullptr, 0, nullptr);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)nblk * 8);
   hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);

@@ -22,8 +22,11 @@
 
 #define NFFT 400
 #define NBIN_PAD 224     // 201 bins padded to 7 MFMA column tiles
-#define FT 32            // frames per workgroup: 50 KB of LDS, so three workgroups share a CU and one's staging /
-                         // mel phases run under the others' MFMA loops (64 frames = 100 KB = one per CU ran 2x slower)
+#define FT 32            // frames per workgroup: 50 KB of LDS; at 200 registers TWO workgroups share a CU and one's staging /
+                         // mel phases run under the other's MFMA loop (64 frames = 100 KB = one per CU ran 2x slower).  Round 3 tried
+                         // three per CU (__launch_bounds__(256, 3), twiddle ring 10 deep, 14 registers spilled, the wave with a single
+                         // column tile rotated over the SIMDs): the median workgroup took 55 us instead of 39 and the launch 145 us
+                         // instead of 147 -- no gain, reverted (tools/micro/logmel_bench.hip prints the phases)
 #define RT (FT / 32)     // 32-frame MFMA row tiles per workgroup
 #define PPITCH 225
 template <int HOP> struct Seg {
