@@ -106,3 +106,16 @@ def test_no_object_holds_the_packed_f32_form_that_fails_beside_mfma_waves(libpat
         bad.write_text(line)
         with pytest.raises(RuntimeError, match="op_sel"):
             B.check_device_asm(str(tmp_path / "x.o"))
+
+
+def test_precision_high_refuses_fp8_weights(libpath):
+    """`model.precision: high` with `model.weight_dtype: fp8` is a contradiction the constructor names (no GPU needed)."""
+    import pytest
+    from wfl_asr_amd import synth
+    from wfl_asr_amd.tagger import BIOPhonemeTagger
+    cfg = synth.baseline_config(4)
+    cfg["model"]["precision"] = "high"
+    with pytest.raises(ValueError, match="contradict"):
+        BIOPhonemeTagger(cfg, synth.make_labels(5))
+    cfg["model"]["weight_dtype"] = "bf16"
+    BIOPhonemeTagger(cfg, synth.make_labels(5))

@@ -94,6 +94,8 @@ class BIOPhonemeTagger:
             a.wavlm_do_normalize = int(w.do_normalize)
         # model.precision: high -- split-precision GEMMs (three bf16 passes, fp32 sums) for callers who need the reference's tag indices
         a.precision = int(str(config["model"].get("precision", "default")).lower() in ("high", "exact"))
+        if a.precision and getattr(a, "fp8_weights", 0):
+            raise ValueError("model.precision: high and model.weight_dtype: fp8 contradict each other (e4m3 weights carry 3 mantissa bits)")
         h = self.head_cfg
         a.num_classes, a.o_id = len(self.label_list), self.label2id["O"]
         a.num_languages, a.lang_emb_dim = h["num_languages"], h["lang_emb_dim"]
