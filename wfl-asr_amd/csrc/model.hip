@@ -224,6 +224,7 @@ struct wfl_model {
   std::vector<Lin> dil;
   Lin cls, off1;
   Lin cls_lo, cls_hi2;             // split-precision classifier: W - bf16(W), and [bf16(W) | bf16(W)] for the [hi | lo] input taps
+  Lin cls3;                        //   and the one-launch form [W_hi | W_hi | W_lo] against the tap segments [h_hi | h_lo | h_hi] (GemmArgs::tap_wrap)
   float *off_w2 = nullptr, *off_b2 = nullptr;
   // profiling
   bool prof_on = false;
@@ -1040,7 +1041,7 @@ static int finalize_head(wfl_model* m, Packer& P) {
   // logits = [h_hi | h_lo] . [W_hi | W_hi]^T + h_hi . W_lo^T + b, three bf16 MFMA passes summed in fp32 -- 0.4 % of the forward's FLOPs
   // for a logit error a plain bf16 pass would double (tests/study_quant.py).
   if (const HostTensor* cw = P.get("classifier.weight", {a.num_classes, d})) {
-    std::vector<float> lo((size_t)a.num_classes * d), hi2((size_t)a.num_classes * 2 * d);
+    std::vector<float> lo((size_t)a.num_classes * d), hi2((size_t)a.num_classes * 2 * d), w3((size_t)a.num_classes * 3 * d);
     for (int n = 0; n < a.num_classes; ++n)
       for (int k = 0; k < d; ++k) {
         const float w = cw->data[(size_t)n * d + k];
@@ -1050,10 +1051,14 @@ static int finalize_head(wfl_model* m, Packer& P) {
         lo[(size_t)n * d + k] = w - wh;
         hi2[(size_t)n * 2 * d + k] = wh;
         hi2[(size_t)n * 2 * d + d + k] = wh;
+        w3[(size_t)n * 3 * d + k] = wh;
+        w3[(size_t)n * 3 * d + d + k] = wh;
+        w3[(size_t)n * 3 * d + 2 * d + k] = w - wh;
       }
     const HostTensor* cb = P.get("classifier.bias", {a.num_classes});
     m->cls_lo = P.pack(lo, a.num_classes, d, nullptr);
     if (cb) m->cls_hi2 = P.pack(hi2, a.num_classes, 2 * d, &cb->data);
+    if (cb && d % 64 == 0) m->cls3 = P.pack(w3, a.num_classes, 3 * d, &cb->data);
   }
   m->off1 = P.conv("boundary_offset_head.0", d, d, 3);
   const HostTensor* w2 = P.get("boundary_offset_head.2.weight", {2, d, 1});
@@ -1205,7 +1210,7 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
   p.stats = take(p.R * 4L * 2 * 4);                     // per row, per 256-column tile (<= 4): (sum, sum of squares)
   p.enc2 = take(p.R * p.d * 2);
   p.clipmax = take((long)B * 4);
-  p.logits = take((long)B * p.T * a.num_classes * 4);
+  p.logits = take((long)B * p.T * round_up(a.num_classes, 4) * 4);      // (rows of a multiple of four floats when the caller does not ask for them)
   p.logits2 = take((long)B * p.T * a.num_classes * 4);
   p.offs2 = take((long)B * p.T * 2 * 4);
   p.gx = p.lstm_x = 0;
@@ -1300,6 +1305,8 @@ struct Runner {
   bool next_lo_out = false;     // the next gemm() produces a residual-stream tensor: keep its low half
   bool next_acc_f32 = false;    // the next gemm() (fp32 output) adds to what is there
   double next_flops = -1.0;     // >= 0: algorithmic FLOPs to book for the next gemm() instead of 2 M N K
+  int next_tap_wrap = 0;        // the next gemm()'s K holds three tap segments (GemmArgs::tap_wrap / seg_off)
+  long next_seg_off = 0;
   // fp8 activations (GemmArgs::a8): the next gemm()'s A operand is e4m3 bytes with these scales / its output goes out as e4m3
   bool next_a8 = false;
   const float* next_a8_scale = nullptr;
@@ -1323,7 +1330,8 @@ struct Runner {
                    clip_ld);
       return;
     }
-    if (precise() && out_f32 && !next_acc_f32 && act == WFL_ACT_NONE && W.W_lo && !W.w8 && !glu && !res && !pos && !clip_bias && !W.ln_s) {
+    if (precise() && out_f32 && !next_acc_f32 && act == WFL_ACT_NONE && W.W_lo && !W.w8 && !glu && !res && !pos && !clip_bias && !W.ln_s &&
+        next_tap_wrap == 0) {
       // fp32 output (the BiLSTM's input projection): the two correction passes first -- A_hi W_lo^T, then A_lo W_hi^T added to it, no
       // bias -- and the plain launch below adds A_hi W_hi^T + b to them
       const bf16_t* A_lo = lo_in(A);
@@ -1348,6 +1356,8 @@ struct Runner {
     stats_in_next = false;
     g.A = A; g.lda = lda;
     g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
+    g.tap_wrap = next_tap_wrap; g.seg_off = next_seg_off;
+    next_tap_wrap = 0; next_seg_off = 0;
     g.W = W.W; g.M = M; g.N = W.N; g.K = W.K; g.n_valid = W.n_valid;
     g.P = P; g.T = T;
     g.clip_T = clip_T_for(P);
@@ -2066,19 +2076,33 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
       }
     }
     float* lg_pass = (n_pass > 1 && pass > 0) ? (float*)(R.ws + p.logits2) : lg;
+    // (the internal logits buffer has rows of a multiple of four floats: the fp32 epilogue then stores 16 bytes at a time instead of
+    //  141 single floats per row; the caller's own buffer and the language-averaging passes keep the compact layout)
+    const long ldlg = (!logits && n_pass == 1) ? round_up(a.num_classes, 4) : a.num_classes;
     // classifier in split precision: h_hi . W_lo^T first, then [h_hi | h_lo] . [W_hi | W_hi]^T + b added to it in fp32 (the two
     // input halves are taps one buffer apart; without a valid low half the second pass is the plain K = d one)
-    R.next_flops = 0.0;
-    R.gemm(H + (long)p.lead * d, d, m->cls_lo, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f,
-           0, 0, false, true);
-    R.next_acc_f32 = true;
-    R.next_flops = 2.0 * (double)B * p.T * (double)a.num_classes * (double)d;
-    if (const bf16_t* hlo = R.lo_in(H))
-      R.gemm(H + (long)p.lead * d, d, m->cls_hi2, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0,
-             1.f, d, (long)(hlo - H), false, true);
-    else
-      R.gemm(H + (long)p.lead * d, d, m->cls, (int)Mrows, p.P, p.T, lg_pass, a.num_classes, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f,
+    static const bool cls_one = std::getenv("WFL_CLS_TWO_LAUNCHES") == nullptr;       // (A/B hook: rounds 2-3's two-launch form)
+    const bf16_t* hlo = R.lo_in(H);
+    if (hlo && m->cls3.W && cls_one) {
+      // one launch (round 3): K' = 3 d over the tap segments [h_hi | h_lo | h_hi] against [W_hi | W_hi | W_lo], bias once, the sum never
+      // leaves the accumulators
+      R.next_flops = 2.0 * (double)B * p.T * (double)a.num_classes * (double)d;
+      R.next_tap_wrap = 1;
+      R.next_seg_off = (long)(hlo - H);
+      R.gemm(H + (long)p.lead * d, d, m->cls3, (int)Mrows, p.P, p.T, lg_pass, ldlg, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f, d, 0, false, true);
+    } else {
+      R.next_flops = 0.0;
+      R.gemm(H + (long)p.lead * d, d, m->cls_lo, (int)Mrows, p.P, p.T, lg_pass, ldlg, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f,
              0, 0, false, true);
+      R.next_acc_f32 = true;
+      R.next_flops = 2.0 * (double)B * p.T * (double)a.num_classes * (double)d;
+      if (hlo)
+        R.gemm(H + (long)p.lead * d, d, m->cls_hi2, (int)Mrows, p.P, p.T, lg_pass, ldlg, 0, p.T, WFL_ACT_NONE, nullptr, 0,
+               1.f, d, (long)(hlo - H), false, true);
+      else
+        R.gemm(H + (long)p.lead * d, d, m->cls, (int)Mrows, p.P, p.T, lg_pass, ldlg, 0, p.T, WFL_ACT_NONE, nullptr, 0, 1.f,
+               0, 0, false, true);
+    }
     R.gemm(H + (long)(p.lead - 1) * d, d, m->off1, (int)Mrows, p.P, p.T, S, d, p.lead, p.P, WFL_ACT_GELU, nullptr, 0, 1.f, d, d);
     if (R.rc) return R.rc;
     TagArgs t{};
@@ -2087,7 +2111,7 @@ static int run_head(Runner& R, const int32_t* lang_id, int32_t lang_mode, float 
     t.hid = S; t.hid_lo = R.lo_in(S); t.ldh = d; t.lead = p.lead; t.P = p.P; t.T = p.T; t.d = d; t.w2 = m->off_w2; t.b2 = m->off_b2;
     t.clip_T = R.clipT; t.Tmax = p.T;
     if (n_pass == 1) {
-      t.logits = lg; t.ldl = a.num_classes; t.offsets = offsets;
+      t.logits = lg; t.ldl = ldlg; t.offsets = offsets;
       t.status_src = (const unsigned*)(R.ws + p.err); t.status_dst = status;
       const int r = wfl_launch_tag_decide(t, R.s);
       if (r) return fail(r, "tag_decide launch failed");
