@@ -40,6 +40,8 @@ import torch
 
 SR = 16000
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0         # same table: ~5 PF dense fp8 (the block-scaled K = 128 forms; the non-scaled fp8 MFMA issues at
+                                      # the bf16 rate, but the roof of an fp8 config is the fp8 roof whichever instruction the build chose)
 # per-GPU batch and clip length of the BASELINE configs (cfg3 64 x 10 s, cfg4 512 / 8, cfg5 256 / 8)
 CONFIG_SHAPE = {1: (16, 30.0), 2: (64, 10.0), 3: (64, 30.0), 4: (32, 30.0)}
 OTHER_KEYS = {2040: "attention (attn_kernel*)", 2041: "BiLSTM recurrence (lstm_kernel)", 2042: "log-mel (logmel_*_kernel)",
@@ -71,7 +73,98 @@ def parse():
                     help="model.precision: high = every GEMM and the attention as three bf16 passes over split operands (the reference's tag indices)")
     ap.add_argument("--full-head", action="store_true",
                     help="Whisper-base + the reference's default config.yaml head (2-layer BiLSTM, 2 Conformer, 2 dilated convs)")
+    ap.add_argument("--no-precision-high", action="store_true",
+                    help="skip the second timed leg (`model.precision: high`, the label-exact mode; default workload only)")
+    ap.add_argument("--high-steps", type=int, default=0, help="steps of the precision-high leg (default: min(steps, 10))")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="walk the launcher and the N-rank host path on CPU (gloo, no GPU, no kernels): shard plan, barrier, one gather "
+                         "of fake packed tags, max-reduce of the clock; prints the JSON line with value null")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (default: a free one)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks ourselves, one process
+    per GPU, as children of this process (which has not touched the GPU and never will), relay their output -- rank 0 prints the
+    one JSON line -- and return the launcher's exit status.  The driver's own form (`python -m torch.distributed.run ... bench.py
+    --gpus N`) arrives with WORLD_SIZE set and never gets here."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args, rank, world):
+    """The host side of an N-rank run without a GPU: gloo rendezvous, the LPT shard plan every rank computes for itself, the fenced
+    timed region with a fake step (a packed tag blob of the real size per rank, ONE gather to rank 0), the max-reduce of the clock
+    and the JSON line.  What it cannot show is a rate."""
+    import torch.distributed as dist
+    from wfl_asr_amd.dist import gather_packed, shard_items, split_packed
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B, clip_seconds = CONFIG_SHAPE[args.config_index]
+    T = 1500 if args.config_index != 2 else 499
+    plan = shard_items([int(clip_seconds * SR)] * (B * world), world)
+    assert sorted(i for p in plan for i in p) == list(range(B * world)) and all(len(p) == B for p in plan)
+    words = B * T * 4 + 1
+    blob = torch.full((words,), rank, dtype=torch.int32)
+    blob[-1] = 0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = gather_packed(blob, dst=0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        assert got.shape == (world, words)
+        for r in range(world):
+            ids, _, _, status = split_packed(got[r], B, T)
+            assert int(ids[0, 0]) == r and int(status[0]) == 0
+        print(json.dumps({"metric": "audio_seconds_labeled_per_sec_per_node", "value": None, "unit": "audio-s/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "dry_launch": True,
+                          "config": {"workload": "dry launch: host path of BASELINE configs[%d] on CPU (gloo), no kernels" % args.config_index,
+                                     "clips_per_gpu": B, "clip_seconds": clip_seconds, "parallelism": f"clip-sharded dp{world}",
+                                     "clips_per_rank": [len(p) for p in plan]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parity_record():
+    """The committed held-out parity record (tests/test_gpu_heldout.py on MI355X: 64 clips, seed 777, product `Labeler` vs the oracle
+    at B = 1, checkpoint as given), quoted beside the two rates so that a reader sees what each mode's labels are worth."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_parity_heldout.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        d["source"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic():
@@ -166,9 +259,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))          # nothing in this process has touched, or will touch, the GPU
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_launch:
+        return dry_launch(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     if args.config_index not in CONFIG_SHAPE:
@@ -221,12 +317,12 @@ def main():
 
     use_graph = args.graph
 
-    def step(graph=use_graph, single=False, x=None):
+    def step(graph=use_graph, single=False, x=None, mdl=None):
         slot = 0 if single else step_no[0] % nfl      # single: the kernel-timing pass runs one batch at a time
         step_no[0] += 1
         host_tags = host_bufs[slot]
         with torch.cuda.stream(streams[slot]):
-            out = model.label(wav if x is None else x, lang, threshold=0.5, graph=graph, slot=slot)
+            out = (mdl or model).label(wav if x is None else x, lang, threshold=0.5, graph=graph, slot=slot)
             if not multi:
                 if not os.environ.get("WFL_BENCH_NO_D2H"):        # (diagnostic: how much the tag copy's blit kernel costs the step)
                     host_tags[0].copy_(out.packed, non_blocking=True)
@@ -330,6 +426,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- second timed leg: the same workload with `model.precision: high` -- the mode whose tag indices are the reference's (the
+    # parity record below); same batch, same fences, every rank, max over ranks.  The headline `value` stays the default build's.
+    high = None
+    if (args.config_index == 1 and not args.full_head and args.precision == "default" and not args.no_precision_high
+            and str(cfg["model"].get("weight_dtype", "bf16")) != "fp8"):
+        import copy
+        cfg_h = copy.deepcopy(cfg)
+        cfg_h["model"]["precision"] = "high"
+        model_h = BIOPhonemeTagger(cfg_h, labels, device=dev)
+        model_h.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        model_h.to(dev).eval()
+        k_h = args.high_steps or min(args.steps, 10)
+        step_no[0] = 0
+        for _ in range(nfl + min(args.warmup, 3)):
+            step(mdl=model_h)
+        fence()
+        step_no[0] = 0
+        th0 = time.perf_counter()
+        for _ in range(k_h):
+            step(mdl=model_h)
+        fence()
+        el_hi = time.perf_counter() - th0
+        check_status()
+        if world > 1:
+            t = torch.tensor([el_hi], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_hi = float(t.item())
+        high = {"value": world * B * clip_seconds * k_h / el_hi, "unit": "audio-s/s", "ms_per_step": 1e3 * el_hi / k_h, "steps": k_h,
+                "dtype": "bf16 pairs (hi + lo operands, three MFMA passes per product, fp32 sums)",
+                "what": "same workload, model.precision: high -- the mode that reproduces the reference's tag indices (parity below)"}
+        del model_h
+
     if rank == 0:
         audio_s = world * B * clip_seconds * args.steps
         m = cfg["model"]
@@ -353,6 +481,8 @@ def main():
                     return "gemm256_kernel<%d, %s, %s, %d>" % (acts[act], tf(glu), tf(f32), 6 if kid == 2 else 8)
                 return "gemm_bf16_kernel<%d, %s, %s>" % (acts[act], tf(glu), tf(f32))
 
+            is_fp8 = str(m.get("weight_dtype", "bf16")) == "fp8"
+            peak = MFMA_FP8_PEAK_TFLOPS if is_fp8 else MFMA_BF16_PEAK_TFLOPS
             gemm = [p for p in prof if p["key"] < 2040]
             other = [p for p in prof if p["key"] >= 2040]
             tot_ms = sum(p["ms"] for p in gemm)
@@ -366,13 +496,13 @@ def main():
                 breakdown[OTHER_KEYS.get(p["key"], str(p["key"]))] = p["ms"] / args.steps
             roof = {
                 "bound": "mfma",
-                "kernel": "MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations; bf16, and for "
-                          "fp8 models the non-scaled fp8 MFMA, which issues at the bf16 rate: same 2.5 PF roof)",
+                "kernel": "MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations)"
+                          + ("; fp8 model: every launch priced against the 5 PF dense fp8 roof" if is_fp8 else "; bf16, 2.5 PF dense roof"),
                 "timing": "HIP events (launch stream) around every launch of a second pass over the same %d steps, run right after the "
                           "timed region, one batch at a time so that no other kernel shares the GPU with the one being timed "
                           "(%.3f ms/step with the events in)" % (args.steps, eager_ms),
-                "achieved": tot_fl / tot_ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tot_fl / tot_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                "achieved": tot_fl / tot_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
+                "frac": tot_fl / tot_ms / 1e9 / peak,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "launches_per_step": tot_n / args.steps, "avg_launch_us": 1e3 * tot_ms / tot_n,
@@ -383,7 +513,7 @@ def main():
                                    "tflops": (p["flops"] / p["ms"] / 1e9) if p["flops"] else None} for p in other],
                 "variants": [
                     {"kernel": kname(p["key"]), "launches": p["launches"], "avg_us": 1e3 * p["ms"] / p["launches"],
-                     "tflops": p["flops"] / p["ms"] / 1e9, "frac": p["flops"] / p["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS}
+                     "tflops": p["flops"] / p["ms"] / 1e9, "frac": p["flops"] / p["ms"] / 1e9 / peak}
                     for p in sorted(gemm, key=lambda p: -p["ms"])],
                 "top_variant": {"kernel": kname(top["key"]), "avg_us": 1e3 * top["ms"] / top["launches"],
                                 "tflops": top["flops"] / top["ms"] / 1e9},
@@ -411,6 +541,11 @@ def main():
         }
         if h2d:
             result.update(h2d)
+        if high:
+            result["precision_high"] = high
+        par = parity_record()
+        if par and args.config_index == 1 and not args.full_head:
+            result["parity"] = par
         if world == 1 and not args.no_cpu_baseline:
             clips = args.cpu_clips or (16 if (args.config_index == 1 and not args.full_head) else 4)
             result["cpu_baseline"] = cpu_baseline(cfg, labels, sd_np, clips, args.cpu_calls, clip_seconds)
