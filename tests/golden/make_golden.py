@@ -16,6 +16,9 @@ Outputs (all small):
   whisper_base_full.npz   Whisper-base + default config.yaml head (BiLSTM x2, Conformer x2, dilated x2)
   wavlm_*.npz             WavLM cases (BASELINE config 1 and a tiny stable-layer-norm variant)
   postprocess.json        outputs of the reference's own host functions on seeded inputs
+  metrics.json            (round 4) train.py's compute_framewise_accuracy / compute_phoneme_error_rate / compute_timing_error / clean_lab
+                          and correct_label.py's correct_lab_boundaries on seeded inputs.  Both modules import here with further EMPTY
+                          stubs for the absent pytorch_optimizer / tensorboard / librosa (none is touched by these functions)
 """
 import json
 import os
@@ -220,9 +223,77 @@ def postprocess_fixture():
     print("postprocess.json:", len(cases), "cases")
 
 
+def metrics_fixture():
+    """/root/reference/train.py:89-148 and correct_label.py:40-87, run as they are on seeded inputs -> metrics.json."""
+    for name in ("pytorch_optimizer", "librosa", "torch.utils.tensorboard"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torch.utils.tensorboard"].SummaryWriter = object
+    import train as ref_train                      # noqa: E402  (the reference, unmodified)
+    import correct_label as ref_cl                 # noqa: E402
+    rng = np.random.RandomState(4321)
+    names = ["a", "b", "en/c", "d", "ja/c", "e", "SP", "en/a"]
+
+    def draw(nmax=14):
+        n = int(rng.randint(0, nmax))
+        t = np.sort(rng.uniform(0, 3, size=2 * n)).reshape(n, 2) if n else np.zeros((0, 2))
+        return [[float(a), float(b), names[int(rng.randint(len(names)))]] for a, b in t]
+
+    seg_cases = []
+    for _ in range(240):
+        p, g = draw(), draw()
+        pt, gt = [tuple(x) for x in p], [tuple(x) for x in g]
+        seg_cases.append(dict(pred=p, gt=g, per=float(ref_train.compute_phoneme_error_rate(pt, gt)),
+                              ter=float(ref_train.compute_timing_error(pt, gt))))
+    acc_cases = []
+    for _ in range(40):
+        B, T, C = int(rng.randint(1, 4)), int(rng.randint(0, 30)), int(rng.randint(2, 12))
+        lg = rng.randn(B, T, C).astype(np.float32)
+        lb = rng.randint(0, C, size=(B, T)).astype(np.int64)
+        if T and rng.rand() < 0.5:                  # make some rows right
+            lb[0] = lg[0].argmax(-1)
+        acc_cases.append(dict(logits=lg.tolist(), labels=lb.tolist(),
+                              acc=float(ref_train.compute_framewise_accuracy(torch.from_numpy(lg), torch.from_numpy(lb)))))
+    clean = [[x, ref_train.clean_lab(x)] for x in ["en/AA", "k", "ja/zh/x", ""]]
+    clean += [[[0.0, 1.0, "ja/k"], ref_train.clean_lab((0.0, 1.0, "ja/k"))], [[0.0, 1.0, ["en/t"]], ref_train.clean_lab((0.0, 1.0, ["en/t"]))]]
+    snap_cases = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for ci in range(220):
+            n = int(rng.randint(0, 16))
+            cuts = np.sort(rng.uniform(0, 4, size=n + 1))
+            segs = [(float(cuts[i]), float(cuts[i + 1]), names[int(rng.randint(len(names)))].split("/")[-1]) for i in range(n)]
+            if n and rng.rand() < 0.3:              # gaps between some segments
+                segs = [(s + 0.004 * (i % 3), e, ph) for i, (s, e, ph) in enumerate(segs)]
+            wav = os.path.join(tmp, "c%d.wav" % ci)
+            lines = ["%d %d %s" % (int(s * 1e7), int(e * 1e7), ph) for s, e, ph in segs]
+            if ci % 7 == 0:
+                lines.insert(len(lines) // 2, "malformed line here too many")     # skipped by the reference (len(parts) != 3)
+            if ci % 11 != 10:                        # (every 11th case has no .lab at all)
+                with open(wav.replace(".wav", ".lab"), "w") as f:
+                    f.write("\n".join(lines) + ("\n" if lines else ""))
+            m = int(rng.randint(0, 24))
+            pred = rng.uniform(0, 4, size=m)
+            # half of the detections sit near real boundaries (inside and just outside the threshold), some are duplicates
+            for k in range(m):
+                if n and rng.rand() < 0.5:
+                    pred[k] = cuts[int(rng.randint(n + 1))] + rng.choice([-0.031, -0.03, -0.012, 0.0, 0.007, 0.0299, 0.03, 0.045])
+            pred = [float(x) for x in (np.sort(pred) if rng.rand() < 0.8 else pred)]
+            if m > 2 and rng.rand() < 0.3:
+                pred[1] = pred[0]
+            thr = [0.03, 0.03, 0.01, 0.05][ci % 4]
+            snapped, orig = ref_cl.correct_lab_boundaries(wav, list(pred), snap_threshold=thr)
+            snap_cases.append(dict(lab_lines=lines if ci % 11 != 10 else None, predicted=pred, snap_threshold=thr,
+                                   snapped=[list(x) for x in snapped], original=[list(x) for x in orig]))
+    with open(os.path.join(HERE, "metrics.json"), "w", encoding="utf-8") as f:
+        json.dump(dict(segments=seg_cases, accuracy=acc_cases, clean_lab=clean, snapping=snap_cases,
+                       default_snap_threshold=ref_cl.snap_threshold_sec), f)
+    print("metrics.json:", len(seg_cases), "segment cases,", len(acc_cases), "accuracy cases,", len(snap_cases), "snapping cases")
+
+
 def main():
     which = set(sys.argv[1:])
     with tempfile.TemporaryDirectory() as tmp:
+        if not which or "metrics" in which:
+            metrics_fixture()
         if not which or "post" in which:
             postprocess_fixture()
         if not which or "tiny" in which:

@@ -10,10 +10,13 @@
 The reference computes the features with librosa 0.11 (`stft`, `feature.mfcc`, `feature.delta`); librosa is not available in this
 image and the reference holds no fixtures for this step, so the feature arithmetic is restated from librosa's documented
 definitions with numpy / scipy and its parity is UNPINNED (only its own properties are tested).  The snapping logic is exact
-Python and is pinned by a worked example.  The two STFTs, the mel / dB / DCT chain and the flux run on the GPU when one is there
+Python and is pinned by 220 outputs of the reference's own function (tests/golden/metrics.json) and a worked example.  The two STFTs, the mel / dB / DCT chain and the flux run on the GPU when one is there
 (csrc/stft.hip through the C ABI: wfl_boundary_features; `device=None` picks it automatically, `device="cpu"` keeps the numpy
 restatement, which the GPU path is tested against); the delta filter, the peak picking and the snapping stay on the host (a few
-thousand values per file).  Input audio must already be 16 kHz (librosa.load would resample with soxr, which is not restated).
+thousand values per file).  A file at another rate is resampled to 16 kHz first, as `librosa.load(path, sr=16000)` does
+(correct_label.py:154) -- with this package's band-limited sinc resampler (audio.resample, the arithmetic of csrc/resample.hip), not
+librosa's soxr: same band limit, different filter, parity UNPINNED like the features'.  A folder is processed by a pool of workers
+like the reference's ProcessPoolExecutor (correct_label.py:200-201): threads here, so that all of them share the one GPU context.
 Like the reference, an interrupted run leaves `<wav>_boundary.txt` behind and the next run reuses it (correct_label.py:89-104,
 153-161); `--save_plot` is not offered (matplotlib plotting is out of scope).
 """
@@ -201,9 +204,11 @@ def write_lab(wav_path, snapped_boundaries, out_path=None):
 def process_file(wav_path, device=None):
     """correct_label.py:153-177 without the plotting: detect (or reuse `<wav>_boundary.txt`), snap, rewrite the `.lab`."""
     y, sr = A.read_wav(wav_path)
+    if y.ndim > 1:
+        y = y.mean(axis=1)                                # librosa.load(mono=True)
     if sr != 16000:
-        raise ValueError("correct_label: 16 kHz input only (librosa.load's soxr resampling is not restated)")
-    y = y.astype(np.float32)
+        y, sr = A.resample(np.asarray(y, dtype=np.float64), int(sr), 16000), 16000     # librosa.load(path, sr=16000)
+    y = np.asarray(y, dtype=np.float32)
     txt = wav_path.replace(".wav", "_boundary.txt")
     if os.path.exists(txt):
         with open(txt) as f:
@@ -224,13 +229,31 @@ def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser(description="Correct .lab timing boundaries from audio features.")
     ap.add_argument("input_path", type=str, help="Path to .wav file or folder containing .wav files")
+    ap.add_argument("--workers", type=int, default=0, help="files in flight in folder mode (default: min(8, host cores))")
     args = ap.parse_args(argv)
     if os.path.isdir(args.input_path):
-        for f in sorted(os.listdir(args.input_path)):
-            if f.endswith(".wav"):
-                process_file(os.path.join(args.input_path, f))
+        process_folder(args.input_path, workers=args.workers)
     else:
         process_file(args.input_path)
+
+
+def process_folder(folder, workers=0, device=None):
+    """Every `*.wav` of a folder, several files in flight (correct_label.py:196-207).  -> {path: snapped segments}; a file that fails
+    is reported and skipped like the reference's `[ERROR]` line, the others still finish."""
+    from concurrent.futures import ThreadPoolExecutor, as_completed
+    wavs = [os.path.join(folder, f) for f in sorted(os.listdir(folder)) if f.endswith(".wav")]
+    workers = workers or max(1, min(8, os.cpu_count() or 1))
+    if device is None and gpu_available() and wavs:
+        boundary_features_gpu(np.zeros(1600, np.float32))      # tables and kernels of the device exist before the workers start
+    out = {}
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        futs = {ex.submit(process_file, w, device): w for w in wavs}
+        for fu in as_completed(futs):
+            try:
+                out[futs[fu]] = fu.result()
+            except Exception as e:                              # noqa: BLE001  (the reference prints and goes on)
+                print(f"[ERROR] Failed to process {futs[fu]}: {e}")
+    return out
 
 
 if __name__ == "__main__":

@@ -8,9 +8,10 @@
   phoneme_name              /root/reference/train.py:89-96
 
 The forward is `model(input_values, lang_ids, max_label_len=...)` (tagger.py: `wfl_encode` -> pad / truncate -> `wfl_head`), the decode is
-the fixture-pinned host logic of postprocess.py.  The metrics are a few lines of host arithmetic each; the reference's own functions
-could not be imported here to generate vectors (its train.py needs tensorboard), so their parity is UNPINNED: tests/test_validate.py
-holds them to hand-computed cases and to the loop-for-loop restatement in oracle/wfl_metrics.py.
+the fixture-pinned host logic of postprocess.py.  The metrics are a few lines of host arithmetic each and are PINNED since round 4:
+tests/golden/metrics.json holds the outputs of the reference's own four functions on 240 seeded segment pairs and 40 logits / label
+tensors (tests/golden/make_golden.py imports train.py with empty stubs for the modules this container lacks); tests/test_validate.py
+holds these functions, and the loop-for-loop restatement in oracle/wfl_metrics.py, to them.
 """
 from __future__ import annotations
 
