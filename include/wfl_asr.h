@@ -77,7 +77,12 @@ typedef struct wfl_arch {
                                         over split operands -- A_hi W_hi + A_hi W_lo + A_lo W_hi, summed in fp32 -- with every activation
                                         carried as a bf16 pair hi + lo: the reference's tag indices at ~2.7x the forward time; the
                                         workspace doubles (wfl_workspace_bytes) */
-  int32_t reserved[7];
+  int32_t fp8_activations;           /* fp8_weights models only ("model.activation_dtype", round 4).  0 (default): bf16 activations -- the e4m3
+                                        weights are the ONLY difference from the bf16 build, which is what holds the reference's arithmetic on
+                                        the fp8-rounded checkpoint (logits within 0.13 / 0.022).  1: the four GEMM inputs of every encoder
+                                        layer are e4m3 too (fp8 x fp8 MFMA): faster, and 5-9 % of the raw tag decisions then differ from that
+                                        reference -- three mantissa bits on the activations; an explicit opt-in */
+  int32_t reserved[6];
 } wfl_arch;
 
 const char* wfl_last_error(void);
@@ -129,7 +134,8 @@ int64_t wfl_workspace_bytes(const wfl_model* m, int32_t B, int32_t L);
  *   start -- and comes out bit for bit as if it were labelled alone; frames behind its own count are tagged o_id with probability 0.
  *   With Whisper, lens only says where a clip's samples end inside the 30 s window (the encoder always sees 1500 frames).
  *   status     [1] int32 (device, optional): 0, or a bit mask of device-side errors of THIS forward (bit 0: an
- *              inter-workgroup wait of the BiLSTM recurrence timed out -- the tags are invalid).  Written by the last kernel
+ *              inter-workgroup wait of the BiLSTM recurrence timed out; bit 1, fp8_activations only: an e4m3 activation saturated
+ *              at its scale or was NaN -- the tags are invalid either way).  Written by the last kernel
  *              of the forward, so it can ride in the same D2H copy as the tags.
  */
 int32_t wfl_forward(wfl_model* m, const float* wav, int64_t ldw, const int32_t* lens, int32_t B, int32_t L,

@@ -143,15 +143,47 @@ def e4m3_rows(x: torch.Tensor) -> torch.Tensor:
     return _e4m3(x * (1.0 / scale)) * scale
 
 
-def whisper_encoder(feats: torch.Tensor, sd: dict, heads: int, layers: int, prefix: str = "encoder.", act_fp8: bool = False,
-                    ff_scale: float = 8.0, att_scale: float = 8.0) -> torch.Tensor:
+def e4m3_blocks(x: torch.Tensor, block: int = 32) -> torch.Tensor:
+    """x as an MX-fp8 operand (OCP microscaling: one e8m0 power-of-two scale per `block` consecutive elements of the last dim, elements
+    e4m3): the block's scale is 2^(floor(log2(max|x|)) - 8), so the largest element lands in [256, 512) before the cast (448 is the
+    format's largest finite value: the cast saturates the top of that octave, as the OCP spec's conversion does)."""
+    sh = x.shape
+    xb = x.reshape(*sh[:-1], sh[-1] // block, block)
+    mx = xb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.where(mx > 0, mx, torch.ones_like(mx)))) - 8.0
+    e = e.clamp(-127.0, 127.0)
+    scale = torch.exp2(e)
+    return (_e4m3(xb / scale) * scale).reshape(sh)
+
+
+def e4m3_pair_blocks(x: torch.Tensor, block: int = 32) -> torch.Tensor:
+    """hi + lo: x rounded to block-scaled e4m3, plus the remainder rounded the same way (its own block scales) -- eight significant
+    bits, what a bf16 operand carries, as two fp8 operands."""
+    hi = e4m3_blocks(x, block)
+    return hi + e4m3_blocks(x - hi, block)
+
+
+ACT_FORMATS = {
+    None: lambda t: t,
+    "bf16": lambda t: t.to(torch.bfloat16).to(torch.float32),
+    "row8": e4m3_rows,
+    "fix8": lambda t: _e4m3(t * 8.0) * (1.0 / 8.0),
+    "blk8": e4m3_blocks,
+    "pair8": e4m3_pair_blocks,
+}
+# the four GEMM inputs of an encoder layer: LayerNorm 1 -> q|k|v, attention context -> out_proj, LayerNorm 2 -> fc1, GELU -> fc2
+ACT_FP8_ROUND3 = {"ln1": "row8", "ctx": "fix8", "ln2": "row8", "gelu": "fix8"}
+
+
+def whisper_encoder(feats: torch.Tensor, sd: dict, heads: int, layers: int, prefix: str = "encoder.", act_fp8=False) -> torch.Tensor:
     """[B, n_mels, 2T] -> [B, T, d].  HF modeling_whisper.py:618-642 (stem 618-625, layers 627-640,
     final LN 642); layer 391-407; attention 309 (q scaled), 332-333 (k no bias), SDPA scaling 1.0.
-    act_fp8 (not the reference: the target of the fp8 x fp8 build, BASELINE configs[4]): the four GEMM inputs of every layer -- both
-    LayerNorm outputs per row, the attention context (head size 64: fixed scale att_scale, else per row) and fc1's GELU output (fixed
-    scale ff_scale) -- rounded to e4m3 exactly
-    where csrc/model.hip rounds them; the checkpoint is expected to be the fp8-rounded one (synth.round_weights_fp8)."""
-    rows8 = e4m3_rows if act_fp8 else (lambda t: t)
+    act_fp8 (NOT the reference -- a diagnostic of what an activation format costs inside the reference's arithmetic; the parity target
+    of the fp8 build is this function with act_fp8 = False on the fp8-rounded checkpoint): a dict naming the format (ACT_FORMATS) of
+    each of the four GEMM inputs of a layer {"ln1", "ctx", "ln2", "gelu"}; True = round 3's choice (ACT_FP8_ROUND3; head size 64)."""
+    if act_fp8 is True:
+        act_fp8 = ACT_FP8_ROUND3
+    fmt = {k: ACT_FORMATS[(act_fp8 or {}).get(k)] for k in ("ln1", "ctx", "ln2", "gelu")}
     p = prefix
     x = F.gelu(F.conv1d(feats, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
     x = F.gelu(F.conv1d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], stride=2, padding=1))
@@ -160,19 +192,15 @@ def whisper_encoder(feats: torch.Tensor, sd: dict, heads: int, layers: int, pref
     hd = d // heads
     for i in range(layers):
         lp = f"{p}layers.{i}."
-        h = rows8(_ln(x, sd, lp + "self_attn_layer_norm"))
+        h = fmt["ln1"](_ln(x, sd, lp + "self_attn_layer_norm"))
         q = (_linear(h, sd, lp + "self_attn.q_proj") * hd ** -0.5).view(B, T, heads, hd).transpose(1, 2)
         k = _linear(h, sd, lp + "self_attn.k_proj").view(B, T, heads, hd).transpose(1, 2)
         v = _linear(h, sd, lp + "self_attn.v_proj").view(B, T, heads, hd).transpose(1, 2)
         a = torch.softmax(q @ k.transpose(2, 3), dim=-1) @ v
-        a = a.transpose(1, 2).reshape(B, T, d)
-        if act_fp8:
-            a = _e4m3(a * att_scale) * (1.0 / att_scale) if hd == 64 else e4m3_rows(a)
+        a = fmt["ctx"](a.transpose(1, 2).reshape(B, T, d))
         x = x + _linear(a, sd, lp + "self_attn.out_proj")
-        h = rows8(_ln(x, sd, lp + "final_layer_norm"))
-        h = F.gelu(_linear(h, sd, lp + "fc1"))
-        if act_fp8:
-            h = _e4m3(h * ff_scale) * (1.0 / ff_scale)
+        h = fmt["ln2"](_ln(x, sd, lp + "final_layer_norm"))
+        h = fmt["gelu"](F.gelu(_linear(h, sd, lp + "fc1")))
         x = x + _linear(h, sd, lp + "fc2")
     return _ln(x, sd, p + "layer_norm")
 

@@ -338,19 +338,7 @@ def test_baseline_configs_3_and_4_vs_oracle(idx, B, L):
     assert bad == 0 and safe.float().mean() >= 0.5
 
 
-@pytest.mark.parametrize("case", ["large_v3_4l", "base_6l"])
-def test_baseline_config_5_fp8_weights_vs_oracle(case):
-    """BASELINE configs[4]: Whisper-large-v3 encoder in fp8 (model.weight_dtype: fp8), linear head.  Since round 3 the four GEMMs of
-    every layer run on v_mfma_f32_16x16x32_fp8_fp8: weights e4m3 with one scale per output channel (round 2), activations e4m3 too
-    -- both LayerNorm outputs and the attention context with one scale per row, fc1's GELU output with a fixed scale.
-    "large_v3_4l" is the real geometry (128 mel bins, d = 1280, 20 heads, FFN 5120) with 4 of the 32 layers so that the CPU oracle
-    finishes in seconds (tests/test_gpu_round2.py holds one row of the full 32-layer, 32-clip forward to the oracle too); "base_6l"
-    runs ALL layers of a smaller fp8 encoder (Whisper-base dims).  Three targets, all outputs of the oracle = the reference's arithmetic:
-      A8  the fp8-rounded checkpoint with the activations rounded to e4m3 where the build rounds them (oracle act_fp8);
-      W8  the fp8-rounded checkpoint, exact activations;
-      F32 the checkpoint as given.
-    The yardstick is the oracle's own A8 - W8 distance (see below): the build must not be further from A8 than 1.25 x that distance
-    (it measures 1.03 x), and tag indices must agree wherever the reference's top-2 margin exceeds 4 tau (8 tau against F32)."""
+def _cfg5_case(case, activation_dtype=None):
     cfg = synth.baseline_config(4)
     assert cfg["model"]["weight_dtype"] == "fp8"
     if case == "large_v3_4l":
@@ -359,6 +347,26 @@ def test_baseline_config_5_fp8_weights_vs_oracle(case):
     else:
         cfg["model"]["whisper_model"] = "local/whisper-base-fp8"
         cfg["model"]["encoder_arch"] = dict(d_model=512, layers=6, heads=8, ffn=2048, n_mels=80, max_positions=1500)
+    if activation_dtype:
+        cfg["model"]["activation_dtype"] = activation_dtype
+    return cfg
+
+
+# What fp8 WEIGHTS cost inside the reference's own arithmetic (oracle on the fp8-rounded checkpoint vs oracle on the checkpoint as
+# given, computed on CPU with no build involved; tests/study_fp8.py): logits 1.51 / 0.315 (large_v3_4l), 1.41 / 0.265 (base_6l); 73 / 183
+# of 1500 raw argmax decisions differ, 18 / 37 of them at a margin above 1 tau, 5 / 4 above 2 tau, none above 4 tau (55 % / 30 % of the
+# frames).  That is the price of BASELINE configs[4]'s "fp8 weights" on these synthetic checkpoints and no kernel can change it: the
+# F32 bounds below are that distance plus the build's own (bf16-sized) share, with the tag rule at 4 tau.
+@pytest.mark.parametrize("case", ["large_v3_4l", "base_6l"])
+def test_baseline_config_5_fp8_weights_vs_oracle(case):
+    """BASELINE configs[4]: Whisper-large-v3 encoder with fp8 weights (model.weight_dtype: fp8), linear head, DEFAULT build = e4m3 weights
+    (one scale per output channel), bf16 activations.  "large_v3_4l" is the real geometry (128 mel bins, d = 1280, 20 heads, FFN 5120)
+    with 4 of the 32 layers so that the CPU oracle finishes in seconds (tests/test_gpu_round2.py holds one row of the full 32-layer,
+    32-clip forward to the oracle too); "base_6l" runs ALL layers of a smaller fp8 encoder (Whisper-base dims).
+    Targets, both outputs of the oracle = the reference's arithmetic, with FIXED bounds (round 4: nothing here is derived from the build):
+      W8  (primary) the reference on the fp8-rounded checkpoint, exact activations: the standard bf16 tolerances and the 1-tau tag rule;
+      F32 the reference on the checkpoint as given: the format's own distance (note above) + the build's share, tag rule at 4 tau."""
+    cfg = _cfg5_case(case)
     m, labels, sd_np = _build(cfg, 70, seed=45)
     B, L = 1, 160000
     wav = synth.make_batch(905, B, L, seed=45)
@@ -366,71 +374,91 @@ def test_baseline_config_5_fp8_weights_vs_oracle(case):
     out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True, want_hidden=True)
     m.check(B, L)
     sd8 = synth.round_weights_fp8(sd_np)
-    refs = {t: _oracle(cfg, labels, sd_t, wav, lang, act_fp8=a8) for t, sd_t, a8 in (("A8", sd8, True), ("W8", sd8, False), ("F32", sd_np, False))}
-    # What the FORMAT costs, measured inside the reference's own arithmetic: the distance between the oracle with and without e4m3
-    # activations.  Rounding to 3 mantissa bits is chaotic -- a relative input change of 1e-3 moves the A8 oracle's own output by as
-    # much as this distance (an e4m3 step is 6-12 % of a value, so a bf16-sized difference in a LayerNorm output flips ~3 % of the
-    # roundings, and a flipped rounding is a whole step) -- so no fp8 build can sit closer to the A8 oracle than about this distance.
-    fmt_h = (refs["A8"][2] - refs["W8"][2]).abs()
-    fmt_l = (refs["A8"][0] - refs["W8"][0]).abs()
-    for target, tmul in (("A8", 4.0), ("W8", 4.0), ("F32", 8.0)):
-        lg, of, hid = refs[target]
+    for target, sd_t, tmul in (("W8", sd8, 1.0), ("F32", sd_np, 4.0)):
+        lg, of, hid = _oracle(cfg, labels, sd_t, wav, lang)
         h_err = (out.hidden.cpu() - hid).abs()
         ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
         err = (out.logits.cpu() - lg).abs()
+        of_err = (out.offsets.cpu() - of).abs().max()
         tau = tmul * TAU * float(lg.std()) / 6.5
         safe = margin > tau
-        bad = int((out.argmax.cpu().long() != arg_ref)[safe].sum())
+        mism = out.argmax.cpu().long() != arg_ref
+        bad, raw = int(mism[safe].sum()), float(mism.float().mean())
         _note(f"cfg5_fp8_{case}_{target}", hidden_max=h_err.max(), hidden_mean=h_err.mean(), logit_std=lg.std(), tau=tau,
-              logits_max=err.max(), logits_mean=err.mean(), offsets_max=(out.offsets.cpu() - of).abs().max(),
-              safe_frac=safe.float().mean(), argmax_bad=bad, argmax_all_mismatch=int((out.argmax.cpu().long() != arg_ref).sum()),
-              frames=int(arg_ref.numel()), format_hidden_mean=fmt_h.mean(), format_logits_mean=fmt_l.mean(), format_logits_max=fmt_l.max())
-        if target == "A8":       # the build adds nothing of its own to what the format costs
-            assert h_err.mean() <= 1.25 * fmt_h.mean() and err.mean() <= 1.25 * fmt_l.mean(), (float(h_err.mean()), float(fmt_h.mean()), float(err.mean()), float(fmt_l.mean()))
-            assert err.max() <= 1.5 * fmt_l.max(), (float(err.max()), float(fmt_l.max()))
-        elif target == "W8":     # two independent roundings of the same size: sqrt(2) of one
-            assert h_err.mean() <= 1.7 * fmt_h.mean() and err.mean() <= 1.7 * fmt_l.mean(), (float(h_err.mean()), float(err.mean()))
+              logits_max=err.max(), logits_mean=err.mean(), offsets_max=of_err, safe_frac=safe.float().mean(), argmax_bad=bad,
+              raw_mismatch_rate=raw, frames=int(arg_ref.numel()))
+        if target == "W8":
+            assert h_err.max() <= 0.08 and h_err.mean() <= 0.012, (float(h_err.max()), float(h_err.mean()))
+            assert err.max() <= 0.40 and err.mean() <= 0.08, (float(err.max()), float(err.mean()))
+            assert of_err <= 0.02
+            assert raw <= 0.02, raw                                 # (the oracle with bf16-rounded GEMM inputs: 0.4 %)
+            assert bad == 0 and safe.float().mean() >= 0.7, (bad, float(safe.float().mean()))
         else:
-            assert h_err.mean() <= 0.15 and err.mean() <= 1.2
-        assert (out.offsets.cpu() - of).abs().max() <= 0.08
-        assert bad == 0, (target, bad)
-        if target != "F32":
-            assert safe.float().mean() >= 0.2                      # (the frames the tag rule grades at 4 tau; at 8 tau -- F32 -- few are left)
+            assert err.max() <= 1.9 and err.mean() <= 0.40, (float(err.max()), float(err.mean()))      # format: 1.51 / 0.315, 1.41 / 0.265
+            assert of_err <= 0.08
+            assert raw <= 0.15, raw                                 # format: 4.9 % / 12.2 %
+            assert bad == 0 and safe.float().mean() >= 0.25, (bad, float(safe.float().mean()))         # graded at 4 tau: 55 % / 30 %
 
 
-def test_fp8_weights_with_bf16_activations_is_still_there(monkeypatch):
-    """WFL_FP8_ACT=0: round 2's form of the fp8 build (e4m3 weights converted in registers, bf16 activations, bf16 MFMA) stays
-    selectable and stays within round 2's tolerances against the oracle on the fp8-rounded checkpoint."""
-    monkeypatch.setenv("WFL_FP8_ACT", "0")
-    cfg = synth.baseline_config(4)
-    cfg["model"]["whisper_model"] = "local/whisper-base-fp8"
-    cfg["model"]["encoder_arch"] = dict(d_model=512, layers=6, heads=8, ffn=2048, n_mels=80, max_positions=1500)
-    import subprocess, sys, textwrap
-    # (the switch is read once per process: a child process)
-    code = textwrap.dedent("""
-        import os, sys, json
-        sys.path.insert(0, %r); sys.path.insert(0, %r)
-        import numpy as np, torch
-        from oracle import wfl_oracle as O
-        from wfl_asr_amd import synth
-        from wfl_asr_amd.archs import resolve_encoder_arch
-        from wfl_asr_amd.tagger import BIOPhonemeTagger
-        cfg = json.loads(%r)
+@pytest.mark.parametrize("case", ["large_v3_4l", "base_6l"])
+def test_fp8_activations_are_an_opt_in_with_a_stated_price(case):
+    """`model.activation_dtype: fp8` (wfl_arch::fp8_activations; round 3's default, an opt-in since round 4): the four GEMM inputs of
+    every encoder layer are e4m3 too and the GEMMs run fp8 x fp8.  Three mantissa bits on the activations are not parity with the
+    reference -- tests/study_fp8.py: the reference's own arithmetic with e4m3 GEMM inputs sits 1.1 / 0.19 (logits max / mean) from
+    itself with exact ones, 82 of 1500 raw argmax decisions differ -- so this mode is held to what it is sold as:
+      * against W8 (the reference on the fp8 checkpoint): logits mean <= 0.30, raw tag mismatch <= 10 %, none above 4 tau;
+      * additionally, against the oracle with the same rounding points (A8, a diagnostic of the format, NOT the reference): the build is
+        not further from it than 1.25 x the format's own A8 - W8 distance, i.e. it adds nothing of its own;
+      * a clean status word (bit 1 = an activation saturated at its fixed scale)."""
+    cfg = _cfg5_case(case, "fp8")
+    m, labels, sd_np = _build(cfg, 70, seed=45)
+    B, L = 1, 160000
+    wav = synth.make_batch(905, B, L, seed=45)
+    lang = np.zeros(B, np.int64)
+    out = m.label(torch.from_numpy(wav).cuda(), lang, threshold=0.5, want_logits=True, want_hidden=True)
+    m.check(B, L)
+    assert int(out.status.item()) == 0
+    sd8 = synth.round_weights_fp8(sd_np)
+    w8 = _oracle(cfg, labels, sd8, wav, lang)
+    a8 = _oracle(cfg, labels, sd8, wav, lang, act_fp8=True)
+    fmt_l = (a8[0] - w8[0]).abs()
+    lg, of, hid = w8
+    ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
+    err = (out.logits.cpu() - lg).abs()
+    mism = out.argmax.cpu().long() != arg_ref
+    safe = margin > 4.0 * TAU * float(lg.std()) / 6.5
+    err_a8 = (out.logits.cpu() - a8[0]).abs()
+    _note(f"cfg5_fp8act_{case}", logits_max=err.max(), logits_mean=err.mean(), raw_mismatch_rate=mism.float().mean(),
+          safe_frac=safe.float().mean(), argmax_bad=int(mism[safe].sum()), format_logits_mean=fmt_l.mean(), format_logits_max=fmt_l.max(),
+          vs_a8_mean=err_a8.mean(), vs_a8_max=err_a8.max())
+    assert err.mean() <= 0.30 and err.max() <= 2.0, (float(err.max()), float(err.mean()))
+    assert float(mism.float().mean()) <= 0.10
+    assert int(mism[safe].sum()) == 0 and safe.float().mean() >= 0.2
+    assert (out.offsets.cpu() - of).abs().max() <= 0.08
+    assert err_a8.mean() <= 1.25 * fmt_l.mean() and err_a8.max() <= 1.5 * fmt_l.max(), (float(err_a8.mean()), float(fmt_l.mean()))
+
+
+def test_fp8_activation_saturation_is_reported():
+    """Advisor (round 3): the fixed scale 8 of the e4m3 attention context / GELU output clipped silently above 56.  A checkpoint whose
+    fc1 bias pushes one GELU channel to ~ 70: the forward must set bit 1 of the status word, `check()` must raise, and the default
+    (bf16 activations) build of the same checkpoint must run clean."""
+    from wfl_asr_amd import _lib
+    for act, want in (("fp8", 2), (None, 0)):
+        cfg = _cfg5_case("base_6l", act)
         labels = synth.make_labels(70)
-        sd_np = synth.make_state_dict(cfg, len(labels), seed=45)
-        m = BIOPhonemeTagger(cfg, labels); m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}); m.to("cuda").eval()
-        wav = synth.make_batch(905, 1, 160000, seed=45)
-        out = m.label(torch.from_numpy(wav).cuda(), np.zeros(1, np.int64), threshold=0.5, want_logits=True)
-        enc, arch = resolve_encoder_arch(cfg["model"])
-        lg, of = O.forward(torch.from_numpy(wav), torch.zeros(1, dtype=torch.long), O.to_torch_state_dict(synth.round_weights_fp8(sd_np)), enc, arch,
-                           synth.head_config(cfg["model"]))
-        err = (out.logits.cpu() - lg).abs()
-        print("RESULT", float(err.max()), float(err.mean()))
-    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), json.dumps(cfg))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, WFL_FP8_ACT="0"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    mx, mean = [float(v) for v in r.stdout.split("RESULT")[1].split()[:2]]
-    assert mx <= 0.40 and mean <= 0.08, (mx, mean)
+        sd_np = synth.make_state_dict(cfg, len(labels), seed=46)
+        b = sd_np["encoder.layers.2.fc1.bias"].copy()
+        b[5] = 70.0
+        sd_np["encoder.layers.2.fc1.bias"] = b
+        m = BIOPhonemeTagger(cfg, labels)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        m.to("cuda").eval()
+        wav = synth.make_batch(906, 1, 48000, seed=46)
+        out = m.label(torch.from_numpy(wav).cuda(), np.zeros(1, np.int64), threshold=0.5)
+        assert int(out.status.item()) & 2 == want, (act, int(out.status.item()))
+        if want:
+            with pytest.raises(_lib.WflError):
+                m.check(1, 48000)
 
 
 def test_graph_replay_is_bit_identical():

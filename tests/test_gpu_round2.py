@@ -212,13 +212,14 @@ def test_full_size_properties_cfg3_cfg4(idx, B, L):
     # ... and the reference at the size that ships: the oracle labels ONE clip of the batch (row 17: second clip group of the recurrence,
     # a rolled and scaled copy of a base clip) alone, at full length, all layers -- seconds of CPU -- and that row of the 64- / 32-clip
     # forward is held to it with the fixed tau rule of test_gpu_model.py (tau = 0.4 * std / 6.5; for the fp8 config the target is the
-    # reference on the fp8-rounded checkpoint with e4m3 activations, target A8 of test_baseline_config_5_fp8_weights_vs_oracle).  Batch invariance (above) ties every
-    # other row of the batch to the same arithmetic.
+    # reference on the fp8-rounded checkpoint with exact activations, target W8 of test_baseline_config_5_fp8_weights_vs_oracle, and the
+    # same fixed bounds as every other config -- round 4: the default fp8 build keeps bf16 activations).  Batch invariance (above) ties
+    # every other row of the batch to the same arithmetic.
     i = 17
     sd_t = synth.round_weights_fp8(_sd) if cfg["model"].get("weight_dtype") == "fp8" else _sd
     enc, arch = resolve_encoder_arch(cfg["model"])
     lg, of = O.forward(torch.from_numpy(wav[i:i + 1]), torch.from_numpy(lang[i:i + 1]), O.to_torch_state_dict(sd_t), enc, arch,
-                       synth.head_config(cfg["model"]), act_fp8=cfg["model"].get("weight_dtype") == "fp8")
+                       synth.head_config(cfg["model"]))
     ids_ref, maxp_ref, arg_ref, margin = O.tags_from_logits(lg, labels.index("O"), 0.5)
     err = (full.logits[i:i + 1].cpu() - lg).abs()
     of_err = (full.offsets[i:i + 1].cpu() - of).abs()
@@ -236,17 +237,11 @@ def test_full_size_properties_cfg3_cfg4(idx, B, L):
                                     frames=int(arg_ref.numel()))) + "\n")
     except OSError:
         pass
-    fp8 = cfg["model"].get("weight_dtype") == "fp8"
-    if fp8:     # e4m3 activations: rounding to 3 mantissa bits is chaotic, the yardstick is the format's own cost (test_gpu_model.py,
-                # test_baseline_config_5_fp8_weights_vs_oracle): here simply 4 tau and the loose absolute bounds measured there x 1.5
-        safe = margin > 4 * tau
-        bad = int((full.argmax[i:i + 1].cpu().long() != arg_ref)[safe].sum())
-        assert float(err.mean()) <= 0.6 and float(of_err.max()) <= 0.1, (float(err.max()), float(err.mean()))
-        assert bad == 0 and float(safe.float().mean()) >= 0.3
-    else:
-        assert float(err.max()) <= 0.40 * max(1.0, std / 6.5) and float(err.mean()) <= 0.08 * max(1.0, std / 6.5), (float(err.max()), float(err.mean()), std)
-        assert float(of_err.max()) <= 0.02
-        assert bad == 0 and float(safe.float().mean()) >= 0.5
+    assert float(err.max()) <= 0.40 * max(1.0, std / 6.5) and float(err.mean()) <= 0.08 * max(1.0, std / 6.5), (float(err.max()), float(err.mean()), std)
+    assert float(of_err.max()) <= 0.02
+    assert bad == 0 and float(safe.float().mean()) >= 0.5
+    if cfg["model"].get("weight_dtype") == "fp8":                  # raw tag mismatch against the fp8-checkpoint reference, stated and bounded
+        assert int((full.argmax[i:i + 1].cpu().long() != arg_ref).sum()) <= 0.03 * arg_ref.numel()
 
 
 def test_outlier_channels_through_the_folded_layernorm_path():

@@ -23,7 +23,7 @@ class WflArch(C.Structure):
         ("wavlm_conv_stride", C.c_int32 * 8), ("wavlm_group_norm", C.c_int32), ("wavlm_conv_bias", C.c_int32),
         ("wavlm_stable_layer_norm", C.c_int32), ("wavlm_pos_conv_kernel", C.c_int32),
         ("wavlm_pos_conv_groups", C.c_int32), ("wavlm_num_buckets", C.c_int32), ("wavlm_max_distance", C.c_int32),
-        ("wavlm_do_normalize", C.c_int32), ("fp8_weights", C.c_int32), ("mel_hop", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("wavlm_do_normalize", C.c_int32), ("fp8_weights", C.c_int32), ("mel_hop", C.c_int32), ("precision", C.c_int32), ("fp8_activations", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 

@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 
   // ---- normalise and store: lane holds channels h*HD + 16dt + 4g + e of query frame q0 + 16qt + c
+  bool sat8 = false;                                 // OUT8: a stored element did not fit e4m3 at the fixed scale -> bit 1 of the error word
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const float l = __shfl(osum[qt][0], c);          // row sum of query c lives in lane (g = 0, c), register 0
@@ -485,7 +486,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int dt = 0; dt < DT; ++dt) {
           float x[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = fminf(fmaxf(o[qt][dt][e] * sc, -448.f), 448.f);
+          for (int e = 0; e < 4; ++e) {
+            const float y = o[qt][dt][e] * sc;
+            sat8 |= !(fabsf(y) <= 448.f);            // (NaN included)
+            x[e] = fminf(fmaxf(y, -448.f), 448.f);
+          }
           int w = 0;
           w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w, false);
           w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
@@ -510,6 +515,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         }
       }
     }
+  }
+  if (OUT8 && p.err) {
+    if (__builtin_amdgcn_ballot_w64(sat8) && lane == 0) atomicOr(p.err, 2u);
   }
 }
 

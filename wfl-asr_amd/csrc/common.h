@@ -69,6 +69,8 @@ struct GemmArgs {
   unsigned char* c8;
   long ldc8;
   float c8_inv_scale;
+  unsigned* err;            // the forward's error word or null: an e4m3 output that saturates (|x| * c8_inv_scale > 448, or NaN) ORs bit 1
+                            //   into it -- a fixed output scale never clips silently (round 4)
   float alpha;              // out = res + alpha * act(v)
   const bf16_t* pos;        // [T][ldpos] added after the activation (positional table) or null
   long ldpos;
@@ -111,6 +113,7 @@ struct AttnArgs {
   unsigned char* O8;
   long ldo8;
   float o8_scale;
+  unsigned* err;          // the forward's error word or null: a context element that saturates e4m3 (or is NaN) ORs bit 1 into it
 };
 
 // One BiLSTM layer's recurrence (lstm.hip)

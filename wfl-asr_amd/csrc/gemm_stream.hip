@@ -374,6 +374,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     }
     char* trash = (char*)p.trash + lane * 16;
     float t1 = 0.f, t2 = 0.f;
+    float amax8 = 0.f;                               // OUT8: largest stored |x| * scale (above 448 it did not fit e4m3)
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
       __builtin_amdgcn_sched_barrier(0);            // one 16-frame tile at a time: keeps the register footprint bounded
@@ -398,8 +399,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         const bool keep = orow[u] >= 0 && nb + 32 * h < p.n_valid;
         if (OUT8) {                                  // e4m3 (saturating at +-448) instead of bf16: 8 bytes per run of 8 channels
           int w0 = 0, w1 = 0;
+          const float keepf = keep ? 1.f : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = fminf(fmaxf(x[e] * p.c8_inv_scale, -448.f), 448.f);
+          for (int e = 0; e < 8; ++e) {
+            const float y = x[e] * p.c8_inv_scale;
+            amax8 = fmaxf(amax8, fabsf(y) * keepf);
+            x[e] = fminf(fmaxf(y, -448.f), 448.f);
+          }
           w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w0, true);
           w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], w1, true);
           char* d8 = (char*)(p.c8 + (long)orow[u] * p.ldc8 + nb + 32 * h);
@@ -432,6 +438,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (RES && u + RING < MT) load_res(u + RING, u % RING);
+    }
+    if (OUT8 && p.err) {                             // (only elements that were stored are judged: halo rows and padding columns are not)
+      if (__builtin_amdgcn_ballot_w64(amax8 > 448.f) && lane == 0) atomicOr(p.err, 2u);
     }
     if (STATS) {
       // The last of the group's four waves to get here adds the four partials of every row in a fixed order (bit-exact

@@ -277,6 +277,9 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (a.enable_dilated && a.dilated_kernel % 2 == 0) return fail(-1, "even dilated_conv_kernel is not supported");
   if (a.fp8_weights && (a.encoder_type != WFL_ENC_WHISPER || a.d_model % 256 || a.enc_ffn % 256))
     return fail(-1, "fp8_weights: Whisper encoders with d_model and ffn multiples of 256 only");
+  if (a.fp8_activations && !a.fp8_weights) return fail(-1, "fp8_activations needs fp8_weights");
+  if (a.fp8_activations < 0 || a.fp8_activations > 1) return fail(-1, "fp8_activations: 0 (bf16) or 1 (e4m3)");
+  if (a.precision && a.fp8_weights) return fail(-1, "precision = 1 (three-pass bf16 pairs) and fp8_weights contradict each other");
   wfl_model* m = new wfl_model();
   m->a = a;
   m->dv = a.d_model;
@@ -1370,6 +1373,7 @@ struct Runner {
     if (next_a8) {
       g.a8 = 1; g.a8_scale = next_a8_scale; g.a8_lead = p.lead; g.a8_static = next_a8_static;
       g.c8 = next_c8; g.ldc8 = next_ldc8; g.c8_inv_scale = next_c8_inv;
+      g.err = (unsigned*)(ws + p.err);
       next_a8 = false; next_a8_scale = nullptr; next_c8 = nullptr;
     }
     if (!out_f32 && !glu && (res || next_lo_out)) g.c_lo = lo_of(C);
@@ -1581,6 +1585,7 @@ struct Runner {
     AttnArgs a{};
     a.bias = bias; a.gate = gate;
     a.O8 = o8; a.ldo8 = ldo8; a.o8_scale = o8_scale;
+    a.err = (unsigned*)(ws + p.err);
     if (precise() && !o8) {                               // the context's low half for the out-projection's third pass
       bf16_t* o_hi = buf(padded ? p.ATTp : p.ATT);
       a.O_lo = lo_of(o_hi);
@@ -1744,8 +1749,12 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     // fp8 x fp8 (BASELINE configs[4]; WFL_FP8_ACT=0: fp8 weights with bf16 activations, round 2's form): every GEMM operand of a layer
     // is e4m3 -- LayerNorm outputs and the attention context with one scale per row (norm.hip), fc1's GELU output straight from its
     // epilogue with a fixed scale -- and the four GEMMs run on v_mfma_f32_16x16x32_fp8_fp8 (gemm_stream.hip, A8)
-    static int fp8_act = -1;
-    if (fp8_act < 0) { const char* e = getenv("WFL_FP8_ACT"); fp8_act = e ? atoi(e) : 1; }
+    // Round 4: e4m3 activations are an explicit opt-in (wfl_arch::fp8_activations, "model.activation_dtype: fp8"); the default for an
+    // fp8-weight model is bf16 activations, which holds the reference's arithmetic on the fp8-rounded checkpoint.  WFL_FP8_ACT=0 / 1
+    // overrides either way (A/B runs).
+    static int fp8_act_env = -2;
+    if (fp8_act_env == -2) { const char* e = getenv("WFL_FP8_ACT"); fp8_act_env = e ? atoi(e) : -1; }
+    const int fp8_act = fp8_act_env >= 0 ? fp8_act_env : a.fp8_activations;
     const bool act8 = a.fp8_weights && fp8_act && p.X8 > 0 && p.ffw == a.enc_ffn;
     for (int i = 0; act8 && i < a.enc_layers; ++i) {
       const EncLayer& L_ = m->enc[i];
@@ -2223,6 +2232,8 @@ int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_
   unsigned err = 0;
   HIPCHK(hipMemcpy(&err, (char*)workspace + p.err, sizeof(unsigned), hipMemcpyDeviceToHost));
   if (err & 1u) return fail(-20, "BiLSTM recurrence: an inter-workgroup wait timed out (results of the last forward are invalid)");
+  if (err & 2u) return fail(-22, "fp8 activations: a value did not fit e4m3 at its scale (results of the last forward are invalid; run this "
+                                 "checkpoint with bf16 activations)");
   if (err) return fail(-21, "device-side error word " + std::to_string(err));
   return 0;
 }

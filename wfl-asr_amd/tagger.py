@@ -43,10 +43,16 @@ class TagBatch:
 
 
 def raise_on_status(word: int):
-    """`word` = TagBatch.status after the forward finished (include/wfl_asr.h: bit 0 = BiLSTM hand-off time-out)."""
+    """`word` = TagBatch.status after the forward finished (include/wfl_asr.h: bit 0 = BiLSTM hand-off time-out, bit 1 = an e4m3
+    activation saturated or was NaN -- `model.activation_dtype: fp8` only)."""
     if word:
+        why = []
+        if int(word) & 1:
+            why.append("a BiLSTM inter-workgroup wait timed out")
+        if int(word) & 2:
+            why.append("an fp8 activation did not fit e4m3 at its scale (model.activation_dtype: fp8; use bf16 activations for this checkpoint)")
         raise _lib.WflError(f"the forward reported a device-side error (status {int(word):#x}"
-                            + (": a BiLSTM inter-workgroup wait timed out" if int(word) & 1 else "") + "); its tags are invalid")
+                            + (": " + "; ".join(why) if why else "") + "); its tags are invalid")
 
 
 class BIOPhonemeTagger:
@@ -79,6 +85,14 @@ class BIOPhonemeTagger:
         elif isinstance(self.arch, WhisperArch):
             a.n_mels, a.max_positions = self.arch.n_mels, self.arch.max_positions
             a.fp8_weights = int(str(config["model"].get("weight_dtype", "bf16")).lower() in ("fp8", "e4m3", "float8_e4m3fn"))
+            # model.activation_dtype (fp8-weight models): bf16 (default -- the reference's arithmetic on the fp8 checkpoint) | fp8 (e4m3
+            # GEMM inputs too: faster, 5-9 % of the raw tag decisions differ; an explicit opt-in since round 4)
+            act = str(config["model"].get("activation_dtype", "bf16")).lower()
+            if act not in ("bf16", "fp8", "e4m3", "float8_e4m3fn"):
+                raise ValueError(f"model.activation_dtype: {act!r} (bf16 or fp8)")
+            if act != "bf16" and not a.fp8_weights:
+                raise ValueError("model.activation_dtype: fp8 needs model.weight_dtype: fp8")
+            a.fp8_activations = int(act != "bf16")
             if (self.arch.n_fft, self.arch.hop) != (400, 160):
                 raise ValueError("the log-mel kernel is built for n_fft=400 / hop=160 (every Whisper checkpoint)")
         else:
