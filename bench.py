@@ -73,7 +73,7 @@ def parse():
                     help="model.precision: high = every GEMM and the attention as three bf16 passes over split operands (the reference's tag indices)")
     ap.add_argument("--full-head", action="store_true",
                     help="Whisper-base + the reference's default config.yaml head (2-layer BiLSTM, 2 Conformer, 2 dilated convs)")
-    ap.add_argument("--activation-dtype", default="bf16", choices=["bf16", "fp8"],
+    ap.add_argument("--activation-dtype", default="bf16", choices=["bf16", "fp8", "fp8_pair", "fp8_nonscaled"],
                     help="--config-index 4 (fp8 weights): model.activation_dtype -- bf16 (default: the reference's arithmetic on the fp8 "
                          "checkpoint) or fp8 (e4m3 GEMM inputs too: faster, 5-9 %% of the raw tags differ; an opt-in)")
     ap.add_argument("--no-precision-high", action="store_true",
@@ -470,7 +470,7 @@ def main():
         roof = None
         if prof:
             acts = {0: 0, 1: 1, 2: 2, 3: 3}
-            fp8_act = str(m.get("weight_dtype", "bf16")) == "fp8" and os.environ.get("WFL_FP8_ACT", "1" if m.get("activation_dtype") == "fp8" else "0") != "0"
+            fp8_act = str(m.get("weight_dtype", "bf16")) == "fp8" and os.environ.get("WFL_FP8_ACT", "0" if m.get("activation_dtype", "bf16") == "bf16" else "1") != "0"
 
             def kname(key):
                 """rocprofv3 kernel name of the template instantiation behind a profile key (model.hip: Runner::gemm)."""
@@ -527,9 +527,10 @@ def main():
             "metric": "audio_seconds_labeled_per_sec_per_node", "value": audio_s / elapsed, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (e4m3 weights and activations in the encoder's GEMMs, fp8 x fp8 MFMA; bf16 elsewhere)"
-                      if os.environ.get("WFL_FP8_ACT", "1" if m.get("activation_dtype") == "fp8" else "0") != "0"
-                      else "bf16 activations x fp8 (e4m3) encoder weights")
+            "dtype": ({"fp8": "fp8 (e4m3 weights, ONE e4m3 value per activation, block-scaled fp8 MFMA; bf16 elsewhere)",
+                       "fp8_pair": "fp8 (e4m3 weights, activations as e4m3 pairs hi + lo, block-scaled fp8 MFMA; bf16 elsewhere)",
+                       "fp8_nonscaled": "fp8 (e4m3 weights and activations, non-scaled fp8 MFMA; bf16 elsewhere)"}.get(
+                           str(m.get("activation_dtype", "bf16")), "bf16 activations x fp8 (e4m3) encoder weights"))
                      if str(m.get("weight_dtype", "bf16")) == "fp8" else
                      ("bf16 pairs (model.precision: high -- hi + lo operands, three MFMA passes, fp32 sums)" if args.precision == "high" else "bf16"),
             "data": "synthetic",

@@ -77,11 +77,16 @@ typedef struct wfl_arch {
                                         over split operands -- A_hi W_hi + A_hi W_lo + A_lo W_hi, summed in fp32 -- with every activation
                                         carried as a bf16 pair hi + lo: the reference's tag indices at ~2.7x the forward time; the
                                         workspace doubles (wfl_workspace_bytes) */
-  int32_t fp8_activations;           /* fp8_weights models only ("model.activation_dtype", round 4).  0 (default): bf16 activations -- the e4m3
-                                        weights are the ONLY difference from the bf16 build, which is what holds the reference's arithmetic on
-                                        the fp8-rounded checkpoint (logits within 0.13 / 0.022).  1: the four GEMM inputs of every encoder
-                                        layer are e4m3 too (fp8 x fp8 MFMA): faster, and 5-9 % of the raw tag decisions then differ from that
-                                        reference -- three mantissa bits on the activations; an explicit opt-in */
+  int32_t fp8_activations;           /* fp8_weights models only ("model.activation_dtype", round 4): how the four GEMM inputs of every encoder
+                                        layer are carried.
+                                        0: bf16 -- the e4m3 weights are converted in registers, bf16 MFMA;
+                                        3: e4m3 PAIRS hi + lo (eight significant bits, what a bf16 operand carries) on the block-scaled
+                                           fp8 MFMA v_mfma_scale_f32_16x16x128_f8f6f4: lo rides in the same instruction with a 2^-4 block
+                                           scale.  Both hold the reference's arithmetic on the fp8-rounded checkpoint (logits within
+                                           0.13 / 0.022);
+                                        2: ONE e4m3 value per activation on the same MFMA: the fastest form, and 5-9 % of the raw tag
+                                           decisions then differ from that reference (three mantissa bits) -- an explicit opt-in;
+                                        1: round 3's form of 2 on the non-scaled fp8 MFMA (kept for A/B runs). */
   int32_t reserved[6];
 } wfl_arch;
 

@@ -5,7 +5,7 @@ error against the fp32 run.  Flags (any combination, comma separated on the comm
   w     weights of every Linear / Conv rounded to bf16
   a     the input of every Linear / Conv rounded to bf16 (what a bf16 MFMA operand is)
   r     the residual stream rounded to bf16 after every residual add (and the stem output)
-  attn  q, k, v and the softmax probabilities rounded to bf16
+  attn  q, k, v and the softmax probabilities rounded to bf16; attn_qk / attn_p / attn_v: only those operands
   r_stem / r_encln / r_lang / r_ln1 / r_enc<i> / r_conf<i>   the residual stream rounded only at that place (encoder layer i, Conformer block i)
   cls   the classifier's input and weight rounded to bf16 (w / a leave the classifier alone)
   wenc / whead   weights of the encoder / of the head (classifier excepted) only
@@ -51,8 +51,11 @@ class Q:
             return bf(t)
         return t
 
-    def at(self, t):
-        return bf(t) if "attn" in self.f else t
+    def at(self, t, what=""):
+        # attn: q, k, v, P all rounded; attn_qk / attn_p / attn_v: only that operand (round 4: which of precision-high's split passes pay)
+        if "attn" in self.f or ("attn_" + what) in self.f or (what in ("q", "k") and "attn_qk" in self.f):
+            return bf(t)
+        return t
 
 
 def lin(q, x, sd, p):
@@ -64,8 +67,8 @@ def conv(q, x, sd, p, **kw):
 
 
 def attn(q_, qh, kh, vh):
-    a = torch.softmax(q_.at(qh) @ q_.at(kh).transpose(2, 3), dim=-1)
-    return q_.at(a) @ q_.at(vh)
+    a = torch.softmax(q_.at(qh, "q") @ q_.at(kh, "k").transpose(2, 3), dim=-1)
+    return q_.at(a, "p") @ q_.at(vh, "v")
 
 
 def forward(q, wav, lang, sd, arch, hc):

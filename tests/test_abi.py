@@ -119,3 +119,34 @@ def test_precision_high_refuses_fp8_weights(libpath):
         BIOPhonemeTagger(cfg, synth.make_labels(5))
     cfg["model"]["weight_dtype"] = "bf16"
     BIOPhonemeTagger(cfg, synth.make_labels(5))
+
+
+def test_precision_high_names_what_a_wide_bilstm_gets(libpath):
+    """Advisor (round 3): `model.precision: high` silently kept the bf16 recurrence for BiLSTMs wider than 256 per direction (cfg3's
+    H = 512, cfg4's H = 384).  Now the constructor refuses that combination unless the caller names it, and says what it built."""
+    import pytest
+    from wfl_asr_amd import synth
+    from wfl_asr_amd.tagger import BIOPhonemeTagger
+    labels = synth.make_labels(5)
+    cfg = synth.baseline_config(3)                      # Whisper-small + full head: BiLSTM hidden 384
+    assert BIOPhonemeTagger(cfg, labels).effective_precision().startswith("default")
+    cfg["model"]["precision"] = "high"
+    with pytest.raises(ValueError, match="precision_wide_bilstm"):
+        BIOPhonemeTagger(cfg, labels)
+    cfg["model"]["precision_wide_bilstm"] = "bf16_recurrence"
+    assert "except the BiLSTM recurrence" in BIOPhonemeTagger(cfg, labels).effective_precision()
+    base = synth.base_config("whisper")                 # Whisper-base + full head: hidden 256, the three-pass recurrence
+    base["model"]["precision"] = "high"
+    assert BIOPhonemeTagger(base, labels).effective_precision().startswith("high (every product")
+    # activation formats of an fp8-weight model: names are checked, fp8 activations need fp8 weights
+    c4 = synth.baseline_config(4)
+    for name in ("bf16", "fp8", "fp8_pair", "fp8_nonscaled"):
+        c4["model"]["activation_dtype"] = name
+        BIOPhonemeTagger(c4, labels)
+    c4["model"]["activation_dtype"] = "int8"
+    with pytest.raises(ValueError, match="activation_dtype"):
+        BIOPhonemeTagger(c4, labels)
+    c1 = synth.baseline_config(1)
+    c1["model"]["activation_dtype"] = "fp8"
+    with pytest.raises(ValueError, match="weight_dtype"):
+        BIOPhonemeTagger(c1, labels)

@@ -15,3 +15,6 @@ P="-O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unu
 /opt/rocm/bin/hipcc $P -DWFL_ABL_ATTN=2 tools/micro/conv0_probe.hip -o tools/micro/conv0_probe_nomfma
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result tools/micro/trans_war_probe.hip -o tools/micro/trans_war_probe
 echo built tools/micro/conv0_probe tools/micro/conv0_probe_noslp tools/micro/conv0_probe_nomfma tools/micro/trans_war_probe
+# round 4: the block-scaled fp8 MFMA's operand / scale layout and issue rate
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result tools/micro/mx_probe.hip -o tools/micro/mx_probe
+echo built tools/micro/mx_probe

@@ -495,6 +495,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w, false);
           w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
           *(int*)(op8 + dt * 16) = w;
+          if (p.O8_lo) {                             // (wave-uniform) the pair's low plane: what the rounding left behind, 16 x
+            typedef __attribute__((ext_vector_type(2))) float f32x2_;
+            const f32x2_ h0 = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), h1 = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+            int wl = 0;
+            wl = __builtin_amdgcn_cvt_pk_fp8_f32(16.f * (x[0] - h0[0]), 16.f * (x[1] - h0[1]), wl, false);
+            wl = __builtin_amdgcn_cvt_pk_fp8_f32(16.f * (x[2] - h1[0]), 16.f * (x[3] - h1[1]), wl, true);
+            *(int*)(p.O8_lo + (op8 - p.O8) + dt * 16) = wl;
+          }
         }
       }
       continue;

@@ -61,12 +61,15 @@ struct GemmArgs {
   // element (m, k) is a8(m, k) * sa(m) with sa(m) = a8_scale[a8_lead + m] (one fp32 scale per A row, written by the kernel that
   // quantised the row) or a8_static when a8_scale is null.  Needs w8_scale; the MFMA is v_mfma_f32_16x16x32_fp8_fp8, both scales
   // multiply the accumulator in the epilogue.
-  int a8;
+  int a8;                   // 1: gemm_stream's A8 form (non-scaled fp8 MFMA); 2 / 3 (round 4, gemm_mx.hip): the block-scaled K = 128 MFMA with
+                            //   A as one e4m3 plane / as an e4m3 PAIR hi + lo (a8_lo: lo = e4m3(16 (x / s - hi)), same lda and scale)
+  const unsigned char* a8_lo;
   const float* a8_scale;
   long a8_lead;
   float a8_static;
   // fp8 OUTPUT (with a8): instead of C, e4m3(out * c8_inv_scale) goes to c8 (ldc8 bytes per row, same row mapping as C)
   unsigned char* c8;
+  unsigned char* c8_lo;     // gemm_mx.hip: the output as an e4m3 pair -- e4m3(16 (out * c8_inv_scale - hi)) goes here (ld = ldc8)
   long ldc8;
   float c8_inv_scale;
   unsigned* err;            // the forward's error word or null: an e4m3 output that saturates (|x| * c8_inv_scale > 448, or NaN) ORs bit 1
@@ -111,6 +114,7 @@ struct AttnArgs {
   // fp8 context (BASELINE configs[4], round 3): instead of O, e4m3(context * o8_scale) goes to O8 (ldo8 bytes per row, same row mapping)
   // -- the out-projection's fp8 operand, with the fixed scale 1 / o8_scale (GemmArgs::a8_static).  head_dim 64 only.
   unsigned char* O8;
+  unsigned char* O8_lo;   // round 4: the context as an e4m3 PAIR -- e4m3(16 (context * o8_scale - hi)) goes here (ld = ldo8), or null
   long ldo8;
   float o8_scale;
   unsigned* err;          // the forward's error word or null: a context element that saturates e4m3 (or is NaN) ORs bit 1 into it
@@ -183,6 +187,8 @@ struct WflOncePerDevice {
 int wfl_launch_gemm(const GemmArgs& a, hipStream_t s);
 // which kernel the last wfl_launch_gemm used (profiling labels): 1 gemm_stream<.,6>, 2 gemm256<.,6>, 3 gemm256<.,8>, 4 gemm_bf16 (128 tile), 5 gemm_stream<.,8>, 6 gemm_stream conv mode
 extern int g_wfl_gemm_kernel_id;
+bool wfl_gemm_mx_takes(const GemmArgs& a);       // gemm_mx.hip: fp8 x fp8 on the block-scaled MFMA (GemmArgs::a8 == 2, 3)
+int wfl_launch_gemm_mx(const GemmArgs& a, hipStream_t s);
 bool wfl_gemm_stream_takes(const GemmArgs& a);   // gemm_stream.hip: would the streaming (LayerNorm-folding) kernel take it
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s);
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,

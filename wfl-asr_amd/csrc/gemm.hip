@@ -375,6 +375,10 @@ int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.N % BN || a.K <= 0 || a.K % BK || a.cin <= 0 || a.cin % BK || a.P <= 0 || a.P % 8 ||
       (!a.out_f32 && a.ldc % 8) || (a.res && a.ldres % 8) || (a.pos && a.ldpos % 8))
     return -1;
+  if (a.a8 >= 2) {                                  // fp8 x fp8 on the block-scaled MFMA (gemm_mx.hip): nothing else reads these operands
+    const int r = wfl_launch_gemm_mx(a, s);
+    return r == 1 ? -1 : r;
+  }
   if (tile_pref() == 256) {
     int r = wfl_launch_gemm_stream(a, s);
     if (r != 1) return r;

@@ -29,6 +29,7 @@
 // alone and 0.59-0.64 us for the real loop.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #define SBK 32
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   auto set_src = [&](int v) __attribute__((always_inline)) {
     int m0, n0;
     tile_of(v, m0, n0);
+    int lane = tid & 63;                             // opaque copy: the lane-dependent parts of the four source pointers are recomputed per
+    asm volatile("" : "+v"(lane));                   //   tile (a few VALU ops) instead of living in registers -- and spilling -- across the K loops
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int wrow = (wid * 2 + i) * 16 + (lane >> 2);
@@ -285,6 +288,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   // ---- epilogue of tile (m0, n0): registers -> HBM
   auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
     const int nb = n0 + wn + 8 * g;                 // first channel of this lane's first run; second run at +32
+    // Opaque bases (round 4): left to itself hipcc computes the MT per-tile row indices and statistics-table addresses once, in front of
+    // the K loop, and keeps them in registers across it -- registers this kernel does not have, so they spill, and a spill's reload inside
+    // the epilogue is an `s_waitcnt vmcnt(0)`: a wait for the operand DMA in flight AND for every store issued so far, in the one place
+    // built around never waiting for a store.  Computed here from values the compiler cannot see through, they cost one add each.
+    int mrow0 = m0 + wm + c;
+    int sidx_w = (((grp * 4 + wq) * (MT * 16)) + c) * 2, sidx_g = ((grp * 4 * (MT * 16)) + c) * 2, sidx_l = (grp * (MT * 16) + c) * 2;
+    asm volatile("" : "+v"(mrow0), "+v"(sidx_w), "+v"(sidx_g), "+v"(sidx_l));
     f32x4 bj[4], sj[4], cj[(W8 || A8) ? 4 : 1];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -298,28 +308,34 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     if (A8) {
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
-        int m = m0 + wm + 16 * u + c;
+        int m = mrow0 + 16 * u;
         m = m < p.M ? m : p.M - 1;
         sa[u] = p.a8_scale ? p.a8_scale[p.a8_lead + m] : p.a8_static;
       }
     }
-    const float invP = 1.0f / (float)p.P;
+    int P_ = p.P, cpitch = p.c_pitch;               // opaque too: 1 / P would otherwise be kept across the K loop
+    asm volatile("" : "+s"(P_), "+s"(cpitch));
+    const float invP = 1.0f / (float)P_;
     int orow[MT];                                   // output row index, or -1 for rows that are not stored
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
-      const int m = m0 + wm + 16 * u + c;
+      const int m = mrow0 + 16 * u;
       int b = (int)((float)m * invP);
-      int t = m - b * p.P;
-      if (t < 0) { t += p.P; --b; }
-      if (t >= p.P) { t -= p.P; ++b; }
-      orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * p.c_pitch + t : -1;
+      int t = m - b * P_;
+      if (t < 0) { t += P_; --b; }
+      if (t >= P_) { t -= P_; ++b; }
+      orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * cpitch + t : -1;
     }
     if (p.clip_T) {                                 // ragged batches: a clip's own frame count (a scalar branch around six loads: inside
 #pragma unroll                                      // the expression above they cost the LayerNorm-folded launches 2 us each)
       for (int u = 0; u < MT; ++u)
         if (orow[u] >= 0) {
-          const int b = (orow[u] - (int)p.c_lead) / p.c_pitch;
-          if (orow[u] - (int)p.c_lead - b * p.c_pitch >= p.clip_T[b]) orow[u] = -1;
+          const int m = mrow0 + 16 * u;             // (clip and frame once more from the row index: an integer division by c_pitch
+          int b = (int)((float)m * invP);           //  would keep its magic reciprocal in a register across the K loop)
+          int t = m - b * P_;
+          if (t < 0) { t += P_; --b; }
+          if (t >= P_) { t -= P_; ++b; }
+          if (t >= p.clip_T[b]) orow[u] = -1;
         }
     }
     // residual hi + lo halves: a ring of three 16-frame tiles in flight (all six at once would not fit the register file next
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     if (LNF == 1) {
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
-        const float2 s = *(const float2*)(stat_lds + (grp * (MT * 16) + u * 16 + c) * 2);
+        const float2 s = *(const float2*)(stat_lds + sidx_l + u * 32);
         mu[u] = s.x;
         rs[u] = s.y;
       }
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       f32x4 sp[MT][2];
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
-        int m = m0 + wm + 16 * u + c;
+        int m = mrow0 + 16 * u;
         m = m < p.M ? m : p.M - 1;
         const f32x4* q = (const f32x4*)(p.stats_in + (p.stats_lead + m) * (2 * SROW));
         sp[u][0] = q[0];
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       if (STATS) {                                   // this wave's 64 columns of frame c: add the four lane groups; the
         t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);   // partial goes to this wave's LDS slot
         t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
-        if (g == 0) *(float2*)(stat_lds + (((grp * 4 + wq) * (MT * 16)) + u * 16 + c) * 2) = float2{t1, t2};
+        if (g == 0) *(float2*)(stat_lds + sidx_w + u * 32) = float2{t1, t2};
         t1 = t2 = 0.f;
       }
 #pragma unroll
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int w4 = 0; w4 < 4; ++w4) {
-          const float2 v = *(const float2*)(stat_lds + (((grp * 4 + w4) * (MT * 16)) + u * 16 + c) * 2);
+          const float2 v = *(const float2*)(stat_lds + sidx_g + w4 * (MT * 32) + u * 32);
           a1 += v.x; a2 += v.y;
         }
         float* sd = p.stats_out + ((long)orow[u] * SROW + (n0 >> 8)) * 2;
@@ -693,6 +709,7 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   return false;
 #endif
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
+  if (a.a8 >= 2) return false;                     // gemm_mx.hip's operands
   if (a.tap_wrap > 0 && (a.ln_s || a.w8_scale || a.a8)) return false;
   if (a.c_lo && !a.res) return false;
   if (a.w8_scale && (a.cin < a.K || a.K % 64)) return false;
@@ -709,6 +726,7 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   if (a.act == WFL_ACT_SIGMOID) return false;
   return true;
 }
+
 
 // Returns 1 when this kernel does not take the launch (caller falls back to gemm256 / gemm).
 int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {

@@ -100,7 +100,7 @@ int wfl_lstm_units_per_wg(int H);
 long wfl_lstm_exchange_bytes(int H, int B);
 bool wfl_lstm_split_precision_supported(int H);
 int wfl_launch_rows_fp8(const bf16_t* x, long ldx, const bf16_t* x_lo, const float* g, const float* b, float eps, long lead, int B, int P,
-                        int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s);          // norm.hip
+                        int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s, unsigned char* y8_lo = nullptr);          // norm.hip
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
 struct ZeroMulti {
   int n;
@@ -278,7 +278,7 @@ int32_t wfl_create(const wfl_arch* arch, wfl_model** out) {
   if (a.fp8_weights && (a.encoder_type != WFL_ENC_WHISPER || a.d_model % 256 || a.enc_ffn % 256))
     return fail(-1, "fp8_weights: Whisper encoders with d_model and ffn multiples of 256 only");
   if (a.fp8_activations && !a.fp8_weights) return fail(-1, "fp8_activations needs fp8_weights");
-  if (a.fp8_activations < 0 || a.fp8_activations > 1) return fail(-1, "fp8_activations: 0 (bf16) or 1 (e4m3)");
+  if (a.fp8_activations < 0 || a.fp8_activations > 3) return fail(-1, "fp8_activations: 0 (bf16), 1 / 2 (e4m3) or 3 (e4m3 pairs)");
   if (a.precision && a.fp8_weights) return fail(-1, "precision = 1 (three-pass bf16 pairs) and fp8_weights contradict each other");
   wfl_model* m = new wfl_model();
   m->a = a;
@@ -1132,6 +1132,7 @@ struct Plan {
   long mel, c1, X, Y, ATT, QK, FF, stats, raw, clipmax, logits, logits2, offs2, gx, lstm_x, enc2;
   long FA, FB, XG, gate, rtab, wstats, cstats, cpart, err, Xlo, Ylo, QKp, ATTp, clipT, total;
   long X8, FF8, rs8;            // fp8 activations (fp8_weights models): e4m3 rows [R][d], [R][ffw], fp32 row scales [R]
+  long X8lo, FF8lo;             //   and their lo planes (e4m3 pairs, gemm_mx.hip)
   long lo_delta, hp32;          // "model.precision: high": every activation buffer has its low half lo_delta bytes further on (a twin of
   long hp32_floats;             //   the whole activation area); hp32 = the fp32 sums of the three passes, [rows][columns]
   int da;                       // Conformer attention width (wfl_model::conf_da); QKp / ATTp exist when it differs from d
@@ -1209,6 +1210,8 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
     p.X8 = take(p.R * (long)p.d);
     p.FF8 = take(p.R * (long)p.ffw);
     p.rs8 = take(p.R * 4L);
+    p.X8lo = take(p.R * (long)p.d);
+    p.FF8lo = take(p.R * (long)p.ffw);
   }
   p.stats = take(p.R * 4L * 2 * 4);                     // per row, per 256-column tile (<= 4): (sum, sum of squares)
   p.enc2 = take(p.R * p.d * 2);
@@ -1315,6 +1318,9 @@ struct Runner {
   const float* next_a8_scale = nullptr;
   float next_a8_static = 1.f;
   unsigned char* next_c8 = nullptr;
+  unsigned char* next_c8_lo = nullptr;            // gemm_mx.hip: e4m3 pair output
+  const unsigned char* next_a8_lo = nullptr;      //   and pair input (next_a8_mode == 3)
+  int next_a8_mode = 1;                           // GemmArgs::a8 of the next launch: 1 gemm_stream A8, 2 / 3 gemm_mx single / pair
   long next_ldc8 = 0;
   float next_c8_inv = 1.f;
   // LayerNorm statistics left behind by the last residual GEMM (gemm_stream.hip, STATS): valid for the rows of `stats_for`
@@ -1371,10 +1377,10 @@ struct Runner {
     g.act = act; g.glu = glu ? 1 : 0; g.out_f32 = out_f32 ? 1 : 0;
     g.acc_f32 = (out_f32 && next_acc_f32) ? 1 : 0;
     if (next_a8) {
-      g.a8 = 1; g.a8_scale = next_a8_scale; g.a8_lead = p.lead; g.a8_static = next_a8_static;
-      g.c8 = next_c8; g.ldc8 = next_ldc8; g.c8_inv_scale = next_c8_inv;
+      g.a8 = next_a8_mode; g.a8_lo = next_a8_lo; g.a8_scale = next_a8_scale; g.a8_lead = p.lead; g.a8_static = next_a8_static;
+      g.c8 = next_c8; g.c8_lo = next_c8_lo; g.ldc8 = next_ldc8; g.c8_inv_scale = next_c8_inv;
       g.err = (unsigned*)(ws + p.err);
-      next_a8 = false; next_a8_scale = nullptr; next_c8 = nullptr;
+      next_a8 = false; next_a8_scale = nullptr; next_c8 = nullptr; next_a8_lo = nullptr; next_c8_lo = nullptr;
     }
     if (!out_f32 && !glu && (res || next_lo_out)) g.c_lo = lo_of(C);
     if (res) g.res_lo = lo_in(res);
@@ -1580,11 +1586,11 @@ struct Runner {
 
   // padded: the Conformer attention at width p.da != p.d (head size rounded up to a built one): q | k | v rows in QKp, context in ATTp
   void attn(int heads, const float* bias = nullptr, const float* gate = nullptr, bool padded = false, unsigned char* o8 = nullptr,
-            long ldo8 = 0, float o8_scale = 1.f) {
+            long ldo8 = 0, float o8_scale = 1.f, unsigned char* o8_lo = nullptr) {
     if (rc) return;
     AttnArgs a{};
     a.bias = bias; a.gate = gate;
-    a.O8 = o8; a.ldo8 = ldo8; a.o8_scale = o8_scale;
+    a.O8 = o8; a.O8_lo = o8_lo; a.ldo8 = ldo8; a.o8_scale = o8_scale;
     a.err = (unsigned*)(ws + p.err);
     if (precise() && !o8) {                               // the context's low half for the out-projection's third pass
       bf16_t* o_hi = buf(padded ? p.ATTp : p.ATT);
@@ -1756,39 +1762,52 @@ static int run_encoder(Runner& R, const float* wav, int64_t ldw, const int32_t* 
     if (fp8_act_env == -2) { const char* e = getenv("WFL_FP8_ACT"); fp8_act_env = e ? atoi(e) : -1; }
     const int fp8_act = fp8_act_env >= 0 ? fp8_act_env : a.fp8_activations;
     const bool act8 = a.fp8_weights && fp8_act && p.X8 > 0 && p.ffw == a.enc_ffn;
+    // fp8_act: 1 single e4m3 activations on gemm_stream's non-scaled fp8 MFMA (round 3); 2 the same on the block-scaled K = 128 MFMA
+    // (gemm_mx.hip, twice the rate); 3 e4m3 PAIRS hi + lo on that MFMA -- eight significant bits per activation, the parity of bf16
+    // activations at the fp8 MFMA's price per pass
+    const bool pair8 = fp8_act == 3;
+    const int a8_mode = fp8_act == 1 ? 1 : (pair8 ? 3 : 2);
     for (int i = 0; act8 && i < a.enc_layers; ++i) {
       const EncLayer& L_ = m->enc[i];
       unsigned char* X8 = (unsigned char*)(R.ws + p.X8);
       unsigned char* FF8 = (unsigned char*)(R.ws + p.FF8);
+      unsigned char* X8lo = pair8 ? (unsigned char*)(R.ws + p.X8lo) : nullptr;
+      unsigned char* FF8lo = pair8 ? (unsigned char*)(R.ws + p.FF8lo) : nullptr;
       float* rs8 = (float*)(R.ws + p.rs8);
-      const float ff_scale = 8.0f;                     // fc1's GELU output is stored as e4m3(8 x): |x| <= 56, normal numbers down to 2^-9
+      // fixed scales of the two operands whose producer cannot see a whole row: single e4m3 stores e4m3(8 x) (|x| <= 56, normal numbers
+      // down to 2^-9); a pair carries eight significant bits, so e4m3(4 x) + lo covers |x| <= 112 down to 2^-13.  A value beyond the
+      // range sets bit 1 of the status word (GemmArgs::err / AttnArgs::err): never a silent clip.
+      const float ff_scale = pair8 ? 4.0f : 8.0f;
+      const float att_scale = pair8 ? 4.0f : 8.0f;
       auto rows8 = [&](const bf16_t* x, const bf16_t* x_lo, const LNp* w) {
         if (R.rc) return;
         R.prof_begin();
-        const int r = wfl_launch_rows_fp8(x, d, x_lo, w ? w->g : nullptr, w ? w->b : nullptr, 1e-5f, p.lead, B, p.P, p.T, d, X8, d, rs8, R.s);
+        const int r = wfl_launch_rows_fp8(x, d, x_lo, w ? w->g : nullptr, w ? w->b : nullptr, 1e-5f, p.lead, B, p.P, p.T, d, X8, d, rs8, R.s, X8lo);
         R.prof_end(2043, 0.0);
         if (r) R.rc = fail(r, "rows_fp8 launch failed");
       };
+      auto next_in = [&](const float* row_scale, float stat, const unsigned char* lo_plane) {
+        R.next_a8 = true; R.next_a8_mode = a8_mode; R.next_a8_scale = row_scale; R.next_a8_static = stat; R.next_a8_lo = lo_plane;
+      };
       rows8(X, R.lo_in(X), &L_.ln1);
-      R.next_a8 = true; R.next_a8_scale = rs8;
+      next_in(rs8, 1.f, X8lo ? X8lo + (long)p.lead * d : nullptr);
       R.gemm((const bf16_t*)(X8 + (long)p.lead * d), d, L_.qkv, (int)Mrows, p.P, p.T, QK, 3 * d, p.lead, p.P, WFL_ACT_NONE);
-      // the attention context leaves the attention kernel as e4m3 with a fixed scale (head_dim 64; other head sizes: bf16, then
-      // quantised per row): a context row is a convex combination of value rows, |x| <= max |v|
-      const float att_scale = 8.0f;
+      // the attention context leaves the attention kernel as e4m3 (a pair in mode 3) with a fixed scale (head_dim 64; other head sizes:
+      // bf16, then quantised per row): a context row is a convex combination of value rows, |x| <= max |v|
       if (d / a.enc_heads == 64) {
-        R.attn(a.enc_heads, nullptr, nullptr, false, X8, d, att_scale);
-        R.next_a8 = true; R.next_a8_scale = nullptr; R.next_a8_static = 1.0f / att_scale;
+        R.attn(a.enc_heads, nullptr, nullptr, false, X8, d, att_scale, X8lo);
+        next_in(nullptr, 1.0f / att_scale, X8lo ? X8lo + (long)p.lead * d : nullptr);
       } else {
         R.attn(a.enc_heads);
         rows8(ATT, nullptr, nullptr);
-        R.next_a8 = true; R.next_a8_scale = rs8;
+        next_in(rs8, 1.f, X8lo ? X8lo + (long)p.lead * d : nullptr);
       }
       R.gemm((const bf16_t*)(X8 + (long)p.lead * d), d, L_.out, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
       rows8(X, R.lo_in(X), &L_.ln2);
-      R.next_a8 = true; R.next_a8_scale = rs8;
-      R.next_c8 = FF8 + (long)p.lead * p.ffw * 0; R.next_ldc8 = p.ffw; R.next_c8_inv = ff_scale;
+      next_in(rs8, 1.f, X8lo ? X8lo + (long)p.lead * d : nullptr);
+      R.next_c8 = FF8; R.next_c8_lo = FF8lo; R.next_ldc8 = p.ffw; R.next_c8_inv = ff_scale;
       R.gemm((const bf16_t*)(X8 + (long)p.lead * d), d, L_.fc1, (int)Mrows, p.P, p.T, FF, p.ffw, p.lead, p.P, WFL_ACT_GELU);
-      R.next_a8 = true; R.next_a8_scale = nullptr; R.next_a8_static = 1.0f / ff_scale;
+      next_in(nullptr, 1.0f / ff_scale, FF8lo ? FF8lo + (long)p.lead * p.ffw : nullptr);
       R.gemm((const bf16_t*)(FF8 + (long)p.lead * p.ffw), p.ffw, L_.fc2, (int)Mrows, p.P, p.T, X, d, p.lead, p.P, WFL_ACT_NONE, X, d, 1.f);
     }
     for (int i = 0; !act8 && i < a.enc_layers; ++i) {

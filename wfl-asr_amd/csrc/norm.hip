@@ -115,7 +115,9 @@ int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const f
 //   layernorm_fp8_kernel   LayerNorm of a residual-stream row (hi + lo) written as e4m3 + scale    (HF modeling_whisper.py:384, 399)
 //   quant_rows_fp8_kernel  bf16 rows (the attention context) -> e4m3 + scale
 // One wave per row, 8 channels per lane per step; scale[row index of the buffer].
-static __device__ __forceinline__ void store_row_fp8(float (*v)[8], int nch, int C, int lane, unsigned char* yp, float* scale_out) {
+// ylo (round 4, the e4m3 PAIR of gemm_mx.hip): what the e4m3 rounding left behind, 16 x, as e4m3 again -- lo = e4m3(16 (x / s - hi))
+static __device__ __forceinline__ void store_row_fp8(float (*v)[8], int nch, int C, int lane, unsigned char* yp, float* scale_out,
+                                                     unsigned char* ylo = nullptr) {
   float mx = 0.f;
   for (int i = 0; i < nch; ++i) {
     const int c0 = (i * 64 + lane) * 8;
@@ -138,6 +140,18 @@ static __device__ __forceinline__ void store_row_fp8(float (*v)[8], int nch, int
       w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
       w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
       *(uint2*)(yp + c0) = make_uint2((unsigned)w0, (unsigned)w1);
+      if (ylo) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2_;
+        const f32x2_ h0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), h1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+        const f32x2_ h2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), h3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+        const float hv[8] = {h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+        int l0 = 0, l1 = 0;
+        l0 = __builtin_amdgcn_cvt_pk_fp8_f32(16.f * (q[0] - hv[0]), 16.f * (q[1] - hv[1]), l0, false);
+        l0 = __builtin_amdgcn_cvt_pk_fp8_f32(16.f * (q[2] - hv[2]), 16.f * (q[3] - hv[3]), l0, true);
+        l1 = __builtin_amdgcn_cvt_pk_fp8_f32(16.f * (q[4] - hv[4]), 16.f * (q[5] - hv[5]), l1, false);
+        l1 = __builtin_amdgcn_cvt_pk_fp8_f32(16.f * (q[6] - hv[6]), 16.f * (q[7] - hv[7]), l1, true);
+        *(uint2*)(ylo + c0) = make_uint2((unsigned)l0, (unsigned)l1);
+      }
     }
   }
   if (lane == 0) *scale_out = scale;
@@ -147,7 +161,7 @@ template <int NCH, bool NORM>
 __global__ __launch_bounds__(256) void rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ x_lo,
                                                        const float* __restrict__ gam, const float* __restrict__ bet, float eps, long lead,
                                                        int B, int P, int T, int C, unsigned char* __restrict__ y8, long ldy8,
-                                                       float* __restrict__ scale) {
+                                                       float* __restrict__ scale, unsigned char* __restrict__ y8_lo) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= (long)B * T) return;
@@ -205,19 +219,19 @@ __global__ __launch_bounds__(256) void rows_fp8_kernel(const bf16_t* __restrict_
       }
     }
   }
-  store_row_fp8(v, NCH, C, lane, y8 + row * ldy8, scale + row);
+  store_row_fp8(v, NCH, C, lane, y8 + row * ldy8, scale + row, y8_lo ? y8_lo + row * ldy8 : nullptr);
 }
 
 // g == null: plain quantisation of the bf16 rows (x_lo is still added when given); else LayerNorm(g, b, eps) first
 int wfl_launch_rows_fp8(const bf16_t* x, long ldx, const bf16_t* x_lo, const float* g, const float* b, float eps, long lead, int B, int P,
-                        int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s) {
+                        int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s, unsigned char* y8_lo) {
   if (C % 8 || ldx % 8 || ldy8 % 8 || C > 2048 || !y8 || !scale) return -1;
   const long rows = (long)B * T;
   const dim3 grid((unsigned)((rows + 3) / 4));
 #define WFL_ROWS8(NCH)                                                                                                                  \
   do {                                                                                                                                  \
-    if (g) hipLaunchKernelGGL((rows_fp8_kernel<NCH, true>), grid, dim3(256), 0, s, x, ldx, x_lo, g, b, eps, lead, B, P, T, C, y8, ldy8, scale);   \
-    else hipLaunchKernelGGL((rows_fp8_kernel<NCH, false>), grid, dim3(256), 0, s, x, ldx, x_lo, g, b, eps, lead, B, P, T, C, y8, ldy8, scale);    \
+    if (g) hipLaunchKernelGGL((rows_fp8_kernel<NCH, true>), grid, dim3(256), 0, s, x, ldx, x_lo, g, b, eps, lead, B, P, T, C, y8, ldy8, scale, y8_lo);   \
+    else hipLaunchKernelGGL((rows_fp8_kernel<NCH, false>), grid, dim3(256), 0, s, x, ldx, x_lo, g, b, eps, lead, B, P, T, C, y8, ldy8, scale, y8_lo);    \
   } while (0)
   if (C <= 512) WFL_ROWS8(1); else if (C <= 1024) WFL_ROWS8(2); else WFL_ROWS8(4);
 #undef WFL_ROWS8

@@ -85,14 +85,16 @@ class BIOPhonemeTagger:
         elif isinstance(self.arch, WhisperArch):
             a.n_mels, a.max_positions = self.arch.n_mels, self.arch.max_positions
             a.fp8_weights = int(str(config["model"].get("weight_dtype", "bf16")).lower() in ("fp8", "e4m3", "float8_e4m3fn"))
-            # model.activation_dtype (fp8-weight models): bf16 (default -- the reference's arithmetic on the fp8 checkpoint) | fp8 (e4m3
-            # GEMM inputs too: faster, 5-9 % of the raw tag decisions differ; an explicit opt-in since round 4)
+            # model.activation_dtype (fp8-weight models; wfl_arch::fp8_activations): bf16 | fp8_pair (e4m3 hi + lo pairs on the
+            # block-scaled fp8 MFMA: bf16's eight significant bits, the reference's arithmetic on the fp8 checkpoint) | fp8 (one e4m3
+            # value per activation: fastest, 5-9 % of the raw tag decisions differ -- an explicit opt-in) | fp8_nonscaled (round 3's kernel)
             act = str(config["model"].get("activation_dtype", "bf16")).lower()
-            if act not in ("bf16", "fp8", "e4m3", "float8_e4m3fn"):
-                raise ValueError(f"model.activation_dtype: {act!r} (bf16 or fp8)")
-            if act != "bf16" and not a.fp8_weights:
+            modes = {"bf16": 0, "fp8_nonscaled": 1, "fp8": 2, "e4m3": 2, "float8_e4m3fn": 2, "fp8_pair": 3, "e4m3_pair": 3}
+            if act not in modes:
+                raise ValueError(f"model.activation_dtype: {act!r} (one of {sorted(modes)})")
+            if modes[act] and not a.fp8_weights:
                 raise ValueError("model.activation_dtype: fp8 needs model.weight_dtype: fp8")
-            a.fp8_activations = int(act != "bf16")
+            a.fp8_activations = modes[act]
             if (self.arch.n_fft, self.arch.hop) != (400, 160):
                 raise ValueError("the log-mel kernel is built for n_fft=400 / hop=160 (every Whisper checkpoint)")
         else:
@@ -110,6 +112,20 @@ class BIOPhonemeTagger:
         a.precision = int(str(config["model"].get("precision", "default")).lower() in ("high", "exact"))
         if a.precision and getattr(a, "fp8_weights", 0):
             raise ValueError("model.precision: high and model.weight_dtype: fp8 contradict each other (e4m3 weights carry 3 mantissa bits)")
+        # The three-pass BiLSTM recurrence holds both halves of its W_hh slice in registers: hidden sizes up to 256 per direction
+        # (csrc/lstm.hip).  A wider BiLSTM (Whisper-small and larger, WavLM-large) keeps the bf16 recurrence between three-pass input
+        # projections -- no longer "the reference's tag indices" -- so that combination is refused unless the caller asks for it by name.
+        self.precision_note = "default (bf16 operands)"
+        if a.precision:
+            self.precision_note = "high (every product three bf16 passes over split operands)"
+            if self.head_cfg["enable_bilstm"] and self.arch.d_model // 2 > 256:
+                if str(config["model"].get("precision_wide_bilstm", "refuse")).lower() != "bf16_recurrence":
+                    raise ValueError(
+                        f"model.precision: high with a BiLSTM of hidden size {self.arch.d_model // 2} per direction: the three-pass recurrence "
+                        "is built for hidden sizes up to 256 (d_model <= 512).  Set model.precision_wide_bilstm: bf16_recurrence to run this "
+                        "model with three-pass GEMMs / attention and the plain bf16 recurrence (measured on Whisper-small + full head: 3 of "
+                        "1500 raw tags differ from the reference, against 0 with the three-pass recurrence on Whisper-base)")
+                self.precision_note = "high except the BiLSTM recurrence (bf16: hidden size > 256 per direction)"
         h = self.head_cfg
         a.num_classes, a.o_id = len(self.label_list), self.label2id["O"]
         a.num_languages, a.lang_emb_dim = h["num_languages"], h["lang_emb_dim"]
@@ -158,6 +174,10 @@ class BIOPhonemeTagger:
 
     def num_frames(self, L: int) -> int:
         return int(self._lib.wfl_num_frames(self._handle, int(L)))
+
+    def effective_precision(self) -> str:
+        """What `model.precision` turned into for this model (a wide BiLSTM under `precision: high` keeps a bf16 recurrence, by request)."""
+        return self.precision_note
 
     def batches_in_flight(self) -> int:
         """How many batches a labelling loop should keep in flight (one stream + workspace slot each).  Two everywhere but one
