@@ -41,6 +41,16 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define MXNCU 256
 
+// Diagnostic build (tools/mx_lab.py, -DWFL_GEMM_STAMPS): per workgroup and wave group, cycles (s_memtime) spent in the prologue, the
+// epilogues, the DMA waits, the barriers and the MFMA issue, written to GemmArgs::stamps[block][group][8] by one lane of each group.
+#if defined(WFL_GEMM_STAMPS) && !defined(MX_STAMPS_LIGHT)
+#define MXT() ((long long)__builtin_amdgcn_s_memtime())
+#define MXACC(var, t0) do { var += MXT() - (t0); } while (0)
+#else
+#define MXT() 0LL
+#define MXACC(var, t0) do { } while (0)
+#endif
+
 static __device__ __forceinline__ void mglds(const char* g, char* l) {
   __builtin_amdgcn_global_load_lds((mgptr_t)g, (mlptr_t)l, 16, 0, 0);
 }
@@ -126,11 +136,15 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
     char* base = smem + islot * STB;
     islot = islot + 1 == R ? 0 : islot + 1;
     const long koff = (long)pkt * KS;
+#ifndef MX_ABL_NODMA            // (diagnostic builds, tools/mx_lab.py: no operand DMA / no fragment reads / no MFMAs -- wrong results, same launch)
 #pragma unroll
     for (int i = 0; i < NA - 1; ++i) mglds(a_src[i] + koff, base + (ap0 + i) * 1024);
     if (a_full) mglds(a_src[NA - 1] + koff, base + (ap0 + NA - 1) * 1024);
 #pragma unroll
     for (int i = 0; i < NW; ++i) mglds(w_src[i] + koff, base + ABYTES + (wid * NW + i) * 1024);
+#else
+    (void)base; (void)koff;
+#endif
     ++issued;
     if (++pkt == nk) {
       pkt = 0;
@@ -147,7 +161,9 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
       if (younger >= 1) { if (stores) mx_wait_vm<(L) + NSTORE>(); else mx_wait_vm<(L)>(); }     \
       else { if (stores) mx_wait_vm<NSTORE>(); else mx_wait_vm<0>(); }                          \
     } while (0)
+#ifndef MX_ABL_NODMA
     if (a_full) MX_WAITY(NA + NW); else MX_WAITY(NA - 1 + NW);
+#endif
 #undef MX_WAITY
   };
 
@@ -294,11 +310,18 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
   };
 
   // ---- prologue: two stages in flight, stage 0 landed, group 1 one barrier behind
+  long long st_ep = 0, st_wait = 0, st_bar = 0, st_mma = 0, st_l = 0;
+#ifdef WFL_GEMM_STAMPS
+  const long long st_t0 = (long long)__builtin_amdgcn_s_memtime();
+#else
+  const long long st_t0 = 0;
+#endif
 #pragma unroll
   for (int t = 0; t < R - 1; ++t) prefetch_one();
   wait_stage(0, false);
   __builtin_amdgcn_s_barrier();
   if (grp) __builtin_amdgcn_s_barrier();
+  const long long st_t1 = MXT();
 
 #define MSB() __builtin_amdgcn_sched_barrier(0)
   i32x8 fw[4], fx[MT];
@@ -311,14 +334,21 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
     const bool last_tile = tv + G >= ntiles;
     for (int kt = 0; kt < nk; ++kt) {
       // ---- L slot (the other group issues its MFMAs meanwhile): the previous tile's epilogue, this stage's fragments, the DMA of stage s + 2
-      if (kt == 0 && have_prev) epilogue(pm0, pn0);
+      long long tq = MXT();
+      if (kt == 0 && have_prev) { epilogue(pm0, pn0); MXACC(st_ep, tq); tq = MXT(); }
       const char* sb = smem + rslot * STB;
+#ifdef MX_ABL_NOLDS
+      if (s == 0)
+#endif
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const i32x4 lo = *(const i32x4*)(sb + w_off[v][0]);
         const i32x4 hi = PAIR ? lo : *(const i32x4*)(sb + w_off[v][PAIR ? 0 : 1]);
         fw[v] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+#ifdef MX_ABL_NOLDS
+      if (s == 0)
+#endif
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
         const i32x4 lo = *(const i32x4*)(sb + x_off[0] + u * 2048), hi = *(const i32x4*)(sb + x_off[1] + u * 2048);
@@ -326,19 +356,29 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
       }
       prefetch_one();
       const bool stores = have_prev && kt < R - 2;    // the epilogue's stores are younger than the stage awaited next
+      MXACC(st_l, tq); tq = MXT();
       if (grp) wait_stage(s + 1, stores);             // group 1 waits before the barrier ...
       __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the fragments are in registers
+      MXACC(st_wait, tq); tq = MXT();
       __builtin_amdgcn_s_barrier();
+      MXACC(st_bar, tq); tq = MXT();
       MSB();
       // ---- C slot
+#ifndef MX_ABL_NOMMA
 #pragma unroll
       for (int u = 0; u < MT; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
           acc[u][v] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[v], fx[u], acc[u][v], 0, 0, 0, scale_w, 0, scale_x);
+#else
+      acc[0][0][0] += (float)fw[0][0] + (float)fx[0][0];
+#endif
       MSB();
+      MXACC(st_mma, tq); tq = MXT();
       if (!grp) wait_stage(s + 1, stores);            // ... group 0 after its MFMAs
+      MXACC(st_wait, tq); tq = MXT();
       if (!(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
+      MXACC(st_bar, tq);
       MSB();
       ++s;
       rslot = rslot + 1 == R ? 0 : rslot + 1;
@@ -346,7 +386,17 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
     pm0 = m0; pn0 = n0;
     have_prev = true;
   }
-  if (have_prev) epilogue(pm0, pn0);
+  {
+    const long long tq = MXT();
+    if (have_prev) epilogue(pm0, pn0);
+    MXACC(st_ep, tq);
+  }
+#ifdef WFL_GEMM_STAMPS
+  if (p.stamps && wq == 0 && lane == 0) {
+    unsigned long long* o = p.stamps + ((long)blockIdx.x * 2 + grp) * 8;
+    o[0] = st_t1 - st_t0; o[1] = (long long)__builtin_amdgcn_s_memtime() - st_t0; o[2] = st_ep; o[3] = st_wait; o[4] = st_bar; o[5] = st_mma; o[6] = st_l; o[7] = s;
+  }
+#endif
 #undef MSB
 }
 
