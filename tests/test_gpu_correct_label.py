@@ -54,3 +54,18 @@ def test_process_file_snaps_a_lab_with_the_gpu_detector(tmp_path):
     assert abs(out[0][0] - times[1]) < 1e-6 and abs(out[0][1] - times[2]) < 1e-6 and abs(out[1][1] - times[3]) < 1e-6
     import os
     assert not os.path.exists(str(tmp_path / "a_boundary.txt"))  # removed once the .lab is rewritten, as the reference does
+
+
+def test_a_ragged_batch_equals_its_clips_one_by_one():
+    """wfl_boundary_features with `lens` (advisor, round 3: flux_kernel ignored lens and reported the step from a short clip's last real
+    frame to its zero padding as flux -- a boundary that does not exist)."""
+    ns = [16000 * 5, 16000 * 2 + 77, 4000]
+    clips = [(synth.make_clip(4400 + i, n, seed=14) * 0.7).astype(np.float32) for i, n in enumerate(ns)]
+    per_clip, flux_all = CL.boundary_features_gpu_batch(clips)
+    for (fb, mb), y, n in zip(per_clip, clips, ns):
+        f1, m1 = CL.boundary_features_gpu(y)
+        assert fb.shape == f1.shape == (1 + n // 160,)
+        assert np.array_equal(fb, f1)                               # same frames, same arithmetic: bit for bit
+        assert np.abs(mb - m1).max() <= 1e-4                        # (top_db floor is per clip: the clip's own maximum either way)
+    for b, n in enumerate(ns):
+        assert np.all(flux_all[b, 1 + n // 160:] == 0.0)            # nothing behind a clip's own frames

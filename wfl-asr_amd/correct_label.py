@@ -123,6 +123,40 @@ def boundary_features_gpu(y, device="cuda"):
     return flux.cpu().numpy(), mfcc.cpu().numpy()
 
 
+def boundary_features_gpu_batch(clips, device="cuda"):
+    """The same features for several 16 kHz clips of different lengths in ONE launch (wfl_boundary_features with `lens`): -> a list of
+    (flux [F_b], mfcc [13, F_b]) with F_b = 1 + len_b // 160, each equal to the clip's own single-clip call."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.device(device)
+    boundary_features_gpu(np.zeros(1600, np.float32), device)          # the device's tables
+    mel_w, dctm = _GPU_TABLES[str(dev)]
+    lens = np.array([len(c) for c in clips], np.int32)
+    B, L = len(clips), int(lens.max())
+    if B == 0 or int(lens.min()) <= 0:
+        raise ValueError("empty batch or empty clip")
+    host = np.zeros((B, L), np.float32)
+    for b, c in enumerate(clips):
+        host[b, :len(c)] = np.asarray(c, dtype=np.float32)
+    F = 1 + L // 160
+    wav = torch.from_numpy(host).to(dev)
+    d_lens = torch.from_numpy(lens).to(dev)
+    flux = torch.empty(B, F, dtype=torch.float32, device=dev)
+    mfcc = torch.empty(B, 13, F, dtype=torch.float32, device=dev)
+    nb = int(lib.wfl_boundary_workspace_bytes(B, L))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    rc = lib.wfl_boundary_features(C.c_void_p(wav.data_ptr()), L, C.c_void_p(d_lens.data_ptr()), B, L, C.c_void_p(mel_w.data_ptr()),
+                                   C.c_void_p(dctm.data_ptr()), C.c_void_p(flux.data_ptr()), C.c_void_p(mfcc.data_ptr()),
+                                   C.c_void_p(ws.data_ptr()), nb, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, "wfl_boundary_features")
+    flux, mfcc = flux.cpu().numpy(), mfcc.cpu().numpy()
+    return [(flux[b, :1 + int(n) // 160], mfcc[b, :, :1 + int(n) // 160]) for b, n in enumerate(lens)], flux
+
+
 def detect_boundaries(y, sr, frame_length=512, hop_length=160, flux_threshold=0.1, delta_window=5, device=None):
     """-> (boundary times [s], flux, mfcc-delta magnitude, frame times), as correct_label.py:15-38.  device: None = the GPU when there
     is one (and the defaults n_fft 512 / hop 160 / 16 kHz are asked for), "cpu" = the numpy restatement."""

@@ -143,6 +143,103 @@ struct LstmArgs {
 #endif
 };
 
+// ---- launch-argument structs shared by a kernel's translation unit and model.hip (round 4: each used to be declared twice)
+// logmel.hip
+struct LogmelArgs {
+  const float* wav; long ldw;       // [B][ldw]
+  const int* lens;                  // [B] valid samples per clip, or null (=L)
+  int L;                            // samples present per row
+  int B, n_samples, n_frames, n_mels;
+  const float* Wc; const float* Ws; // [200][224] folded tables: row j-1 <-> n = j (1..200)
+  const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
+  float* raw;                       // [B][n_frames][n_mels] log10 mel
+  unsigned* clipmax;                // [B] ordered-uint max of raw (zeroed by the caller)
+#ifdef WFL_LOGMEL_STAMPS
+  unsigned long long* stamps;       // diagnostic build (tools/micro/logmel_bench.hip): [blocks][8] 100 MHz phase stamps
+#endif
+};
+
+// precise.hip
+struct PreciseFinishArgs {
+  const float* acc; long ld_acc;          // [B * P rows][ld_acc]: the three passes' sum (rows b * P + t)
+  int B, P, T, n_out;                     // output columns (GLU: half the accumulator's)
+  int glu;                                // accumulator columns interleaved in groups of 16: (a | gate) -> a * sigmoid(gate)
+  const float* bias;                      // [N of the accumulator] or null
+  const float* clip_bias; const int* clip_idx; int clip_ld;
+  int act; float alpha;
+  const bf16_t* pos; long ldpos;          // [T][ldpos] added after the activation, or null
+  const bf16_t* pos_lo;                   //   and the table's low half (same layout), or null
+  const bf16_t* res; const bf16_t* res_lo; long ldres;     // residual rows (same row mapping as the output) or null
+  bf16_t* out; bf16_t* out_lo; long ldc; long c_lead; int c_pitch;
+  const int* clip_T;                      // ragged batches: rows t >= clip_T[b] are not stored
+};
+
+// head.hip
+struct TagArgs {
+  const float* logits; long ldl;     // [rows][C] fp32, rows = B*T compact
+  int rows, C;
+  float threshold; int o_id;
+  int* ids;                          // argmax, or o_id when max prob < threshold
+  int* argmax;                       // raw argmax (may be null)
+  float* maxprob;
+  // offsets (optional)
+  const bf16_t* hid; long ldh; long lead; int P, T, d;   // frame rows of the offset head's hidden activation
+  const bf16_t* hid_lo;              //   precision high: their low halves (same layout) or null
+  const float* w2;                   // [2][d]
+  const float* b2;                   // [2]
+  float* offsets;                    // [rows][2]
+  const unsigned* status_src;        // the forward's device-side error word -> *status_dst (both optional)
+  int* status_dst;
+  const int* clip_T; int Tmax;       // [clips] valid frames per clip (rows = clips x Tmax) or null: frames beyond a clip's own count are
+                                     //   tagged "O" with probability 0 and zero offsets, whatever the logits buffer holds there
+};
+
+// wavlm.hip
+struct Conv0Args {
+  const float* wav; long ldw; int L;      // [B][ldw]
+  const double* wstats;                   // [B][2] sum, sumsq of the waveform, or null (do_normalize off)
+  const float* w;                         // [C][10]
+  const float* bias;                      // [C] or null
+  const float* gamma; const float* beta;  // [C]
+  int B, T0, C;
+  const int* lens;                        // [B] samples per clip or null (= L): statistics, the conv's input range and the frame count
+                                          //   (len - 10) / 5 + 1 follow the clip's own length
+  double* cstats;                         // [B][C][2] (group mode)
+  float* cpart;                           // [B][time blocks][C][2] per-workgroup partial sums (group mode, pass 1)
+  bf16_t* out; long lead; int P;          // frame rows [.., C]
+  bf16_t* out_lo;                         // precision high: the rows' low halves (same layout) or null
+};
+
+// posconv.hip
+struct PosConvArgs {
+  const bf16_t* xg;               // [groups][R][64] regrouped rows (zero outside valid frames / channels)
+  long R;                         // rows per group
+  long lead;                      // row of (clip 0, frame 0)
+  int B, P, T;                    // flat frame m = b * P + t, stored iff t < T
+  int groups, cpg, taps;          // channels per group (<= 64, % 8 == 0), taps (even, <= 128)
+  const bf16_t* w[16];            // per group [>= cpg rows][ldw]: k = tap * 64 + channel
+  const float* bias[16];          // per group [>= cpg]
+  long ldw;
+  const bf16_t* res;              // x rows (ld), its low half (or null)
+  const bf16_t* res_lo;
+  bf16_t* out;                    // y rows (ld), low half (or null)
+  bf16_t* out_lo;
+  long ld;
+  const int* clip_T;              // [B] valid frames per clip or null
+};
+
+// norm.hip
+struct ZeroMulti {
+  int n;
+  char* buf[10];
+  long ld_bytes[10];
+  long lead[10];
+  int P[10], T[10];
+  long tail_rows[10];
+  int B;
+  unsigned* err_word;   // the forward's device-side error word, cleared here (first kernel of every forward); may be null
+};
+
 // erf GELU (nn.GELU() default / HF "gelu"):  gelu(x) = max(x, 0) - |x| * Phi(-|x|),  Phi(-t) = 0.5 * erfc(t / sqrt 2).
 // log2 Phi(-t) is smooth and nearly quadratic, so Phi(-t) = exp2(q(t)) with q a degree-5 minimax fit on [0, 6] weighted
 // by the error it causes in gelu (tools/fit_gelu.py): |gelu error| <= 6.4e-7 over all x in fp32 (the bf16 rounding of the

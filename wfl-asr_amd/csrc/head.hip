@@ -4,24 +4,7 @@
 //   offsets:      /root/reference/model.py:139-141 Conv1d(d -> 2, k=1) + Sigmoid on the GELU'd k=3 conv output
 #include "common.h"
 
-struct TagArgs {
-  const float* logits; long ldl;     // [rows][C] fp32, rows = B*T compact
-  int rows, C;
-  float threshold; int o_id;
-  int* ids;                          // argmax, or o_id when max prob < threshold
-  int* argmax;                       // raw argmax (may be null)
-  float* maxprob;
-  // offsets (optional)
-  const bf16_t* hid; long ldh; long lead; int P, T, d;   // frame rows of the offset head's hidden activation
-  const bf16_t* hid_lo;              //   precision high: their low halves (same layout) or null
-  const float* w2;                   // [2][d]
-  const float* b2;                   // [2]
-  float* offsets;                    // [rows][2]
-  const unsigned* status_src;        // the forward's device-side error word -> *status_dst (both optional)
-  int* status_dst;
-  const int* clip_T; int Tmax;       // [clips] valid frames per clip (rows = clips x Tmax) or null: frames beyond a clip's own count are
-                                     //   tagged "O" with probability 0 and zero offsets, whatever the logits buffer holds there
-};
+// (struct TagArgs: common.h -- one definition for the kernel and for model.hip)
 
 __global__ __launch_bounds__(256) void tag_decide_kernel(TagArgs p) {
   const int lane = threadIdx.x & 63;

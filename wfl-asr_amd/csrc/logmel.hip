@@ -39,19 +39,7 @@ template <int HOP> struct Seg {
 #define LSTAMP(k) do { } while (0)
 #endif
 
-struct LogmelArgs {
-  const float* wav; long ldw;       // [B][ldw]
-  const int* lens;                  // [B] valid samples per clip, or null (=L)
-  int L;                            // samples present per row
-  int B, n_samples, n_frames, n_mels;
-  const float* Wc; const float* Ws; // [200][224] folded tables: row j-1 <-> n = j (1..200)
-  const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
-  float* raw;                       // [B][n_frames][n_mels] log10 mel
-  unsigned* clipmax;                // [B] ordered-uint max of raw (zeroed by the caller)
-#ifdef WFL_LOGMEL_STAMPS
-  unsigned long long* stamps;       // diagnostic build (tools/micro/logmel_bench.hip): [blocks][8] 100 MHz phase stamps
-#endif
-};
+// (struct LogmelArgs: common.h -- one definition for the kernel and for model.hip)
 
 static __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);

@@ -16,77 +16,19 @@
 #include <vector>
 
 // ---- launchers defined in the kernel translation units
-struct LogmelArgs {
-  const float* wav; long ldw;
-  const int* lens;
-  int L;
-  int B, n_samples, n_frames, n_mels;
-  const float* Wc; const float* Ws;
-  const int* mel_lo; const int* mel_cnt; const float* mel_w; int mel_maxw;
-  float* raw;
-  unsigned* clipmax;
-};
 int wfl_launch_logmel(const LogmelArgs& a, bf16_t* out, long ldo, long lead, int P, float* ref_out, hipStream_t s, bf16_t* out_lo = nullptr);
-struct PreciseFinishArgs {                 // precise.hip ("model.precision: high")
-  const float* acc; long ld_acc;
-  int B, P, T, n_out;
-  int glu;
-  const float* bias;
-  const float* clip_bias; const int* clip_idx; int clip_ld;
-  int act; float alpha;
-  const bf16_t* pos; long ldpos;
-  const bf16_t* pos_lo;
-  const bf16_t* res; const bf16_t* res_lo; long ldres;
-  bf16_t* out; bf16_t* out_lo; long ldc; long c_lead; int c_pitch;
-  const int* clip_T;
-};
 int wfl_launch_precise_finish(const PreciseFinishArgs& a, hipStream_t s);
 int wfl_launch_melpower(const LogmelArgs& a, int hop, bf16_t* out, long ldo, long lead, int P, int split, int shift, hipStream_t s);
 
-struct TagArgs {
-  const float* logits; long ldl;
-  int rows, C;
-  float threshold; int o_id;
-  int* ids;
-  int* argmax;
-  float* maxprob;
-  const bf16_t* hid; long ldh; long lead; int P, T, d;
-  const bf16_t* hid_lo;
-  const float* w2;
-  const float* b2;
-  float* offsets;
-  const unsigned* status_src;   // the forward's device-side error word -> *status_dst (both optional)
-  int* status_dst;
-  const int* clip_T; int Tmax;
-};
 int wfl_launch_tag_decide(const TagArgs& a, hipStream_t s);
 int wfl_launch_f32_to_rows(const float* in, bf16_t* x, long ldx, long lead, int B, int P, int T, int C, hipStream_t s, int split,
                            int shift, bf16_t* x_lo = nullptr);
 
 int wfl_launch_lstm(LstmArgs a, void* exchange, hipStream_t s);
 
-struct Conv0Args {
-  const float* wav; long ldw; int L;
-  const double* wstats;
-  const float* w;
-  const float* bias;
-  const float* gamma; const float* beta;
-  int B, T0, C;
-  const int* lens;
-  double* cstats;
-  float* cpart;
-  bf16_t* out; long lead; int P;
-  bf16_t* out_lo;
-};
 int wfl_launch_wav_stats(const float* wav, long ldw, int B, int L, double* stats, hipStream_t s, const int* lens = nullptr);
 int wfl_launch_conv0(const Conv0Args& a, int group_norm, hipStream_t s);
 int wfl_launch_clip_frames(const int* lens, int B, int L, int n, const int* kernel, const int* stride, int min_len, int* out, hipStream_t s);
-struct PosConvArgs {               // posconv.hip
-  const bf16_t* xg; long R; long lead; int B, P, T; int groups, cpg, taps;
-  const bf16_t* w[16]; const float* bias[16]; long ldw;
-  const bf16_t* res; const bf16_t* res_lo; bf16_t* out; bf16_t* out_lo; long ld;
-  const int* clip_T;
-};
 int wfl_launch_posconv(const PosConvArgs& a, hipStream_t s);
 int wfl_launch_regroup(const bf16_t* x, int d, int groups, int cpg, long R, long lead, int B, int P, int T, bf16_t* xg, hipStream_t s,
                        const int* clip_T = nullptr);
@@ -102,16 +44,6 @@ bool wfl_lstm_split_precision_supported(int H);
 int wfl_launch_rows_fp8(const bf16_t* x, long ldx, const bf16_t* x_lo, const float* g, const float* b, float eps, long lead, int B, int P,
                         int T, int C, unsigned char* y8, long ldy8, float* scale, hipStream_t s, unsigned char* y8_lo = nullptr);          // norm.hip
 int wfl_launch_axpy(float* dst, const float* src, long n, float alpha, int init, hipStream_t s);
-struct ZeroMulti {
-  int n;
-  char* buf[10];
-  long ld_bytes[10];
-  long lead[10];
-  int P[10], T[10];
-  long tail_rows[10];
-  int B;
-  unsigned* err_word;   // the forward's device-side error word, cleared here (first kernel of every forward); may be null
-};
 int wfl_launch_zero_halo_multi(const ZeroMulti& z, hipStream_t s);
 int wfl_launch_rows_to_f32(const bf16_t* x, long ldx, long lead, int B, int P, int T, int C, float* out, hipStream_t s, int split,
                            int shift, const bf16_t* x_lo = nullptr);

@@ -347,16 +347,7 @@ int wfl_launch_copy16(void* dst, const void* src, long bytes, hipStream_t s) {
 }
 
 // One launch for all frame-row buffers of a forward (same clip geometry per entry, different widths / pitches).
-struct ZeroMulti {
-  int n;
-  char* buf[10];
-  long ld_bytes[10];
-  long lead[10];
-  int P[10], T[10];
-  long tail_rows[10];
-  int B;
-  unsigned* err_word;   // the forward's device-side error word, cleared here (first kernel of every forward); may be null
-};
+// (struct ZeroMulti: common.h -- one definition for the kernel and for model.hip)
 
 __global__ __launch_bounds__(256) void zero_halo_multi_kernel(ZeroMulti z) {
   const int k = blockIdx.y;

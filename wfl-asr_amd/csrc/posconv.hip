@@ -26,22 +26,7 @@ typedef __attribute__((address_space(3))) void* pc_lptr_t;
 #define PC_NST 4                  // weight ring depth
 #define PC_LDS (2 * PC_EXT_BYTES + PC_NST * PC_WST_BYTES)
 
-struct PosConvArgs {
-  const bf16_t* xg;               // [groups][R][64] regrouped rows (zero outside valid frames / channels)
-  long R;                         // rows per group
-  long lead;                      // row of (clip 0, frame 0)
-  int B, P, T;                    // flat frame m = b * P + t, stored iff t < T
-  int groups, cpg, taps;          // channels per group (<= 64, % 8 == 0), taps (even, <= 128)
-  const bf16_t* w[16];            // per group [>= cpg rows][ldw]: k = tap * 64 + channel
-  const float* bias[16];          // per group [>= cpg]
-  long ldw;
-  const bf16_t* res;              // x rows (ld), its low half (or null)
-  const bf16_t* res_lo;
-  bf16_t* out;                    // y rows (ld), low half (or null)
-  bf16_t* out_lo;
-  long ld;
-  const int* clip_T;              // [B] valid frames per clip or null
-};
+// (struct PosConvArgs: common.h -- one definition for the kernel and for model.hip)
 
 static __device__ __forceinline__ int pc_sswz(int row) { return (-(row >> 2)) & 3; }              // aligned 16-row reads (weights)
 static __device__ __forceinline__ int pc_xswz(int row) { return ((row >> 2) & 1) << 1; }          // 16-row reads from ANY start row

@@ -13,19 +13,7 @@
 // as hi AND lo.  HBM-bound element-wise work.
 #include "common.h"
 
-struct PreciseFinishArgs {
-  const float* acc; long ld_acc;          // [B * P rows][ld_acc]: the three passes' sum (rows b * P + t)
-  int B, P, T, n_out;                     // output columns (GLU: half the accumulator's)
-  int glu;                                // accumulator columns interleaved in groups of 16: (a | gate) -> a * sigmoid(gate)
-  const float* bias;                      // [N of the accumulator] or null
-  const float* clip_bias; const int* clip_idx; int clip_ld;
-  int act; float alpha;
-  const bf16_t* pos; long ldpos;          // [T][ldpos] added after the activation, or null
-  const bf16_t* pos_lo;                   //   and the table's low half (same layout), or null
-  const bf16_t* res; const bf16_t* res_lo; long ldres;     // residual rows (same row mapping as the output) or null
-  bf16_t* out; bf16_t* out_lo; long ldc; long c_lead; int c_pitch;
-  const int* clip_T;                      // ragged batches: rows t >= clip_T[b] are not stored
-};
+// (struct PreciseFinishArgs: common.h -- one definition for the kernel and for model.hip)
 
 __global__ __launch_bounds__(256) void precise_finish_kernel(PreciseFinishArgs p) {
   const int chunks = p.n_out / 8;                                   // 8 output columns per thread

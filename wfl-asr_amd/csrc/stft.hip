@@ -84,14 +84,18 @@ __global__ __launch_bounds__(256) void stft_kernel(StftArgs p) {
   }
 }
 
-// flux[b][t] = sqrt(sum_k (S[t][k] - S[t-1][k])^2), flux[b][0] = 0 (np.pad(flux, (1,)) then cut to the frame count)
-__global__ __launch_bounds__(256) void flux_kernel(const float* __restrict__ S, int B, int F, int nbins, float* __restrict__ flux) {
+// flux[b][t] = sqrt(sum_k (S[t][k] - S[t-1][k])^2), flux[b][0] = 0 (np.pad(flux, (1,)) then cut to the frame count).  A clip shorter
+// than the batch (lens) has 1 + len / hop frames: the frames behind them are zero in S, and so is the flux there -- in particular at the
+// first such frame, where the difference to the clip's last real frame would otherwise show up as a boundary that does not exist.
+__global__ __launch_bounds__(256) void flux_kernel(const float* __restrict__ S, int B, int F, int nbins, const int* __restrict__ lens,
+                                                   float* __restrict__ flux) {
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= (long)B * F) return;
   const int t = (int)(i % F);
+  const int nf = lens ? 1 + lens[i / F] / SHOP : F;
   float acc = 0.f;
-  if (t > 0) {
+  if (t > 0 && t < nf) {
     const float* a = S + i * nbins;
     const float* p = a - nbins;
     for (int k = lane; k < nbins; k += 64) { const float d = a[k] - p[k]; acc = fmaf(d, d, acc); }
@@ -225,7 +229,7 @@ int32_t wfl_boundary_features(const float* wav, int64_t ldw, const int32_t* lens
   a.Wc = t2048.Wc; a.Ws = t2048.Ws; a.nbins = 1025; a.nb_pad = t2048.nb_pad; a.out = P; a.power = 1;
   if (int r = launch_stft<2048>(a, s)) return r;
   const long rows = (long)B * F;
-  hipLaunchKernelGGL(flux_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, B, F, 257, flux);
+  hipLaunchKernelGGL(flux_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, B, F, 257, lens, flux);
   hipLaunchKernelGGL(clear_u32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, cmax, B);
   hipLaunchKernelGGL(mel_db_kernel, dim3((unsigned)((rows * 128 + 255) / 256)), dim3(256), 0, s, P, B, F, 1025, mel_w, 128, lens, L, LM, cmax);
   hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)((rows * 13 + 255) / 256)), dim3(256), 0, s, LM, cmax, B, F, 128, dct, 13, mfcc);

@@ -37,20 +37,7 @@ __global__ __launch_bounds__(1024) void wav_stats_kernel(const float* __restrict
   }
 }
 
-struct Conv0Args {
-  const float* wav; long ldw; int L;      // [B][ldw]
-  const double* wstats;                   // [B][2] sum, sumsq of the waveform, or null (do_normalize off)
-  const float* w;                         // [C][10]
-  const float* bias;                      // [C] or null
-  const float* gamma; const float* beta;  // [C]
-  int B, T0, C;
-  const int* lens;                        // [B] samples per clip or null (= L): statistics, the conv's input range and the frame count
-                                          //   (len - 10) / 5 + 1 follow the clip's own length
-  double* cstats;                         // [B][C][2] (group mode)
-  float* cpart;                           // [B][time blocks][C][2] per-workgroup partial sums (group mode, pass 1)
-  bf16_t* out; long lead; int P;          // frame rows [.., C]
-  bf16_t* out_lo;                         // precision high: the rows' low halves (same layout) or null
-};
+// (struct Conv0Args: common.h -- one definition for the kernel and for model.hip)
 
 static __device__ __forceinline__ void wav_norm(const Conv0Args& p, int b, float& mean, float& rstd) {
   mean = 0.f; rstd = 1.f;
