@@ -121,9 +121,10 @@ def test_precision_high_refuses_fp8_weights(libpath):
     BIOPhonemeTagger(cfg, synth.make_labels(5))
 
 
-def test_precision_high_names_what_a_wide_bilstm_gets(libpath):
+def test_precision_high_and_activation_formats_are_validated(libpath):
     """Advisor (round 3): `model.precision: high` silently kept the bf16 recurrence for BiLSTMs wider than 256 per direction (cfg3's
-    H = 512, cfg4's H = 384).  Now the constructor refuses that combination unless the caller names it, and says what it built."""
+    H = 512, cfg4's H = 384).  Round 4 built the three-pass recurrence for them (csrc/lstm.hip, the four-wave form); what is left to refuse
+    is a hidden size beyond 640, and the constructor says what it built."""
     import pytest
     from wfl_asr_amd import synth
     from wfl_asr_amd.tagger import BIOPhonemeTagger
@@ -131,13 +132,12 @@ def test_precision_high_names_what_a_wide_bilstm_gets(libpath):
     cfg = synth.baseline_config(3)                      # Whisper-small + full head: BiLSTM hidden 384
     assert BIOPhonemeTagger(cfg, labels).effective_precision().startswith("default")
     cfg["model"]["precision"] = "high"
-    with pytest.raises(ValueError, match="precision_wide_bilstm"):
-        BIOPhonemeTagger(cfg, labels)
-    cfg["model"]["precision_wide_bilstm"] = "bf16_recurrence"
-    assert "except the BiLSTM recurrence" in BIOPhonemeTagger(cfg, labels).effective_precision()
-    base = synth.base_config("whisper")                 # Whisper-base + full head: hidden 256, the three-pass recurrence
-    base["model"]["precision"] = "high"
-    assert BIOPhonemeTagger(base, labels).effective_precision().startswith("high (every product")
+    assert BIOPhonemeTagger(cfg, labels).effective_precision().startswith("high (every product")
+    wide = synth.baseline_config(3)
+    wide["model"].update(whisper_model="local/too-wide", precision="high")
+    wide["model"]["encoder_arch"] = dict(d_model=1536, layers=2, heads=24, ffn=6144, n_mels=80, max_positions=1500)
+    with pytest.raises(ValueError, match="640"):
+        BIOPhonemeTagger(wide, labels)
     # activation formats of an fp8-weight model: names are checked, fp8 activations need fp8 weights
     c4 = synth.baseline_config(4)
     for name in ("bf16", "fp8", "fp8_pair", "fp8_nonscaled"):

@@ -43,7 +43,9 @@ def main():
         f.write("\n".join(labels) + "\n")
     with open(os.path.join(cfg["output"]["save_dir"], "langs.txt"), "w") as f:
         f.write("en,0\nja,1\n")
-    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, len(labels), seed=1).items()}
+    # (the WavLM-large + BiLSTM stack leaves the synthetic classifier's input ~11 x smaller than Whisper-base's does: at the usual gain no
+    #  tag ever crosses the confidence threshold and the decode / merge / .lab legs of the run would have nothing to do)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, len(labels), seed=1, cls_gain=66.0 if args.wavlm else 6.0).items()}
     wavs = os.path.join(d, "wavs")
     os.makedirs(wavs)
     base = [synth.make_clip(5000 + i, 480000, seed=1) * 0.8 for i in range(8)]

@@ -77,10 +77,15 @@ typedef __attribute__((address_space(3))) void* lstm_lptr_t;
 // length (every Whisper batch) that cost 3.85 against 3.25 ms per 16-clip forward (A/B on one box, default head).
 // SPLIT ("model.precision: high", LstmArgs::whh_lo / out_lo): W_hh and h as bf16 pairs hi + lo -- the low halves of W_hh in registers
 // beside the high ones, h_t published as two granules (a second image behind the first), gates += W_hi h_hi + W_lo h_hi + W_hi h_lo.
-template <int H, int MAXT, bool RAG, bool SPLIT = false>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
-__global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
+// SELFGX (round 4): no loader wave -- 256 threads, ONE wave per SIMD, so a wave may hold up to 512 registers: the split-precision recurrence
+// of hidden sizes above 256 (Whisper-small's 384, WavLM-large's 512, Whisper-large's 640), whose W_hh slice needs H / 2 registers per wave
+// for its two halves.  Every compute wave streams the gx of its own tiles itself (LDS-DMA into its own part of the ring, LSTM_DL steps
+// ahead, issued right BEHIND a step's poll so that only the next step's poll has to retire it): the +0.2 .. 0.4 us per step the loader
+// wave was introduced to remove is the price of the exact mode here.  No barrier is involved: a wave reads back only what it fetched.
+template <int H, int MAXT, bool RAG, bool SPLIT = false, bool SELFGX = false>     // MAXT = MFMA tiles per wave (even: tiles come in even / odd unit pairs)
+__global__ __launch_bounds__(SELFGX ? 256 : LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   static_assert(MAXT % 2 == 0, "tiles are paired");
-  static_assert(!SPLIT || H <= 256, "split precision: both halves of the W_hh slice stay in registers");
+  static_assert(!SPLIT || H <= 256 || SELFGX, "split precision: both halves of the W_hh slice stay in registers (above 256: one wave per SIMD)");
   constexpr int KS = H / 32;                     // K steps of 32 hidden units
   constexpr int NP = MAXT / 2;                   // tile pairs per wave
   __shared__ bf16x8 hfrag[2][KS][64];            // h_{t-1} as MFMA B fragments: [parity][K step][lane]
@@ -192,7 +197,22 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   // its own vmcnt; it joins the compute waves' one barrier per step, in front of which it has seen step s + 1's data land.
   const float* gx_lane = p.gx + (p.lead + (long)clip_rd * p.P) * p.ldgx + dir * 4 * H + 4 * (slice * U + 2 * g);
   const int Tc = RAG ? p.clip_T[clip_rd] : p.T;          // frames of this lane's clip (LstmArgs::clip_T)
-  if (wid == 4) {
+  auto issue_own_gx = [&](int s) __attribute__((always_inline)) {       // SELFGX: this wave's own tiles of step s
+    int t = dir == 0 ? s : Tc - 1 - s;
+    if (RAG) t = s < Tc ? t : 0;
+    const float* gp = gx_lane + (long)t * p.ldgx;
+    char* dst = lstm_dyn + (long)(s & (LSTM_NR - 1)) * (4 * MAXT * 1024);
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int pp = wid + 4 * (i >> 1) < npair ? wid + 4 * (i >> 1) : npair - 1;
+      __builtin_amdgcn_global_load_lds((lstm_gptr_t)(gp + 4 * (8 * pp + (i & 1))), (lstm_lptr_t)(dst + (wid * MAXT + i) * 1024), 16, 0, LSTM_GX_AUX);
+    }
+  };
+  if (SELFGX) {
+    for (int s = 0; s < LSTM_DL && s < p.T; ++s) issue_own_gx(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (!SELFGX && wid == 4) {
     auto issue = [&](int s) __attribute__((always_inline)) {
       int t = dir == 0 ? s : Tc - 1 - s;             // (this lane's clip: its backward direction starts at its own last frame)
       if (RAG) t = s < Tc ? t : 0;                   // steps beyond the clip's length: any valid row, the result is never stored
@@ -316,6 +336,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
         }
 #endif
       }
+      // SELFGX: the gx of step s + LSTM_DL, behind this step's poll (whose wait retired everything older, the DMA of steps <= s + LSTM_DL - 1
+      // included) and in front of the next one's
+      if (SELFGX && s + LSTM_DL < p.T) issue_own_gx(s + LSTM_DL);
       __syncthreads();
       LSTAMP(2);
       if (dflag) dead = true;
@@ -328,6 +351,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
         for (int ks = 0; ks < KS; ++ks) hfl[ks] = hfrag_lo[par][ks][lane];
       }
     } else {
+      if (SELFGX && LSTM_DL < p.T) issue_own_gx(LSTM_DL);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) hf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // h_{-1} = 0
       if (SPLIT) {
@@ -398,33 +422,36 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_kernel(LstmArgs p) {
   for (int s = 0; s < p.T; ++s) step(s);
 }
 
-template <int H, int MAXT, bool RAG, bool SPLIT = false>
+template <int H, int MAXT, bool RAG, bool SPLIT = false, bool SELFGX = false>
 static int launch_lstm_r(const LstmArgs& a, int groups, hipStream_t s) {
   const int teams = 2 * groups;
   constexpr int lds = LSTM_NR * 4 * MAXT * 1024;       // the gx ring (dynamic; the fragment images are static shared memory)
-  auto k = lstm_kernel<H, MAXT, RAG, SPLIT>;
+  constexpr int NTHREADS = SELFGX ? 256 : LSTM_THREADS;
+  auto k = lstm_kernel<H, MAXT, RAG, SPLIT, SELFGX>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
 #ifdef WFL_LSTM_STAMPS
-  hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + a.team_shift + 7) / 8)), dim3(LSTM_THREADS), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + a.team_shift + 7) / 8)), dim3(NTHREADS), lds, s, a);
 #else
-  hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + 7) / 8)), dim3(LSTM_THREADS), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(8 * a.G * ((teams + 7) / 8)), dim3(NTHREADS), lds, s, a);
 #endif
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 template <int H, int MAXT>
 static int launch_lstm_t(const LstmArgs& a, int groups, hipStream_t s) {
-  if constexpr (H <= 256) {
-    if (a.whh_lo && a.out_lo)
+  if (a.whh_lo && a.out_lo) {
+    if constexpr (H <= 256)
       return a.clip_T ? launch_lstm_r<H, MAXT, true, true>(a, groups, s) : launch_lstm_r<H, MAXT, false, true>(a, groups, s);
+    else       // both halves of the slice no longer fit 256 registers: four waves, one per SIMD, no loader wave
+      return a.clip_T ? launch_lstm_r<H, MAXT, true, true, true>(a, groups, s) : launch_lstm_r<H, MAXT, false, true, true>(a, groups, s);
   }
   return a.clip_T ? launch_lstm_r<H, MAXT, true>(a, groups, s) : launch_lstm_r<H, MAXT, false>(a, groups, s);
 }
 
-bool wfl_lstm_split_precision_supported(int H) { return H <= 256; }
+bool wfl_lstm_split_precision_supported(int H) { return H <= 640; }
 
 // Units per WG: 32 (four waves x one pair of 16-row tiles) when it divides H, else the largest multiple of 8 below that does.
 // Measured at H = 256, 16 clips (tools/micro/lstm_bench.hip): 64 units per WG (4 WGs per direction) 2.14 us per step, 32 units

@@ -112,20 +112,15 @@ class BIOPhonemeTagger:
         a.precision = int(str(config["model"].get("precision", "default")).lower() in ("high", "exact"))
         if a.precision and getattr(a, "fp8_weights", 0):
             raise ValueError("model.precision: high and model.weight_dtype: fp8 contradict each other (e4m3 weights carry 3 mantissa bits)")
-        # The three-pass BiLSTM recurrence holds both halves of its W_hh slice in registers: hidden sizes up to 256 per direction
-        # (csrc/lstm.hip).  A wider BiLSTM (Whisper-small and larger, WavLM-large) keeps the bf16 recurrence between three-pass input
-        # projections -- no longer "the reference's tag indices" -- so that combination is refused unless the caller asks for it by name.
+        # The three-pass BiLSTM recurrence holds both halves of its W_hh slice in registers (csrc/lstm.hip): hidden sizes up to 256 per
+        # direction with the loader wave, up to 640 (Whisper-small's 384, WavLM-large's 512, Whisper-large's 640) in the four-wave form
+        # that has 512 registers per wave (round 4).  Beyond that the recurrence would silently stay bf16: refused.
         self.precision_note = "default (bf16 operands)"
         if a.precision:
             self.precision_note = "high (every product three bf16 passes over split operands)"
-            if self.head_cfg["enable_bilstm"] and self.arch.d_model // 2 > 256:
-                if str(config["model"].get("precision_wide_bilstm", "refuse")).lower() != "bf16_recurrence":
-                    raise ValueError(
-                        f"model.precision: high with a BiLSTM of hidden size {self.arch.d_model // 2} per direction: the three-pass recurrence "
-                        "is built for hidden sizes up to 256 (d_model <= 512).  Set model.precision_wide_bilstm: bf16_recurrence to run this "
-                        "model with three-pass GEMMs / attention and the plain bf16 recurrence (measured on Whisper-small + full head: 3 of "
-                        "1500 raw tags differ from the reference, against 0 with the three-pass recurrence on Whisper-base)")
-                self.precision_note = "high except the BiLSTM recurrence (bf16: hidden size > 256 per direction)"
+            if self.head_cfg["enable_bilstm"] and self.arch.d_model // 2 > 640:
+                raise ValueError(f"model.precision: high with a BiLSTM of hidden size {self.arch.d_model // 2} per direction: the three-pass "
+                                 "recurrence is built for hidden sizes up to 640 (d_model <= 1280)")
         h = self.head_cfg
         a.num_classes, a.o_id = len(self.label_list), self.label2id["O"]
         a.num_languages, a.lang_emb_dim = h["num_languages"], h["lang_emb_dim"]
