@@ -35,7 +35,7 @@ def build(name, flags):
     drv = os.path.join(OUT, "drv.hip")
     open(drv, "w").write(DRV)
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-DWFL_GEMM_STAMPS", "-mllvm",
-           "-amdgpu-mfma-vgpr-form=1", "-I", SRC, *flags, "-shared", os.path.join(SRC, "gemm.hip"), os.path.join(SRC, "gemm256.hip"), os.path.join(SRC, "gemm_stream.hip"),
+           "-amdgpu-mfma-vgpr-form=1", "-I", SRC, *flags, "-shared", os.path.join(SRC, "gemm.hip"), os.path.join(SRC, "gemm256.hip"), os.path.join(SRC, "gemm_stream.hip"), os.path.join(SRC, "gemm_mx.hip"),
            drv, "-o", lib]
     subprocess.run(cmd, check=True)
     return lib

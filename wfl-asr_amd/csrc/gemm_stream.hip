@@ -300,9 +300,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
+#ifdef WFL_ABL_EPI_NOLOAD       // (diagnostic, tools/gemm_lab.py: the epilogue without its operand loads -- what waiting for them behind the DMA costs)
+        bj[2 * h + q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (LNF) sj[2 * h + q] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (W8 || A8) cj[2 * h + q] = (f32x4){1.f, 1.f, 1.f, 1.f};
+#else
         bj[2 * h + q] = p.bias ? *(const f32x4*)(p.bias + nb + 32 * h + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (LNF) sj[2 * h + q] = *(const f32x4*)(p.ln_s + nb + 32 * h + 4 * q);
         if (W8 || A8) cj[2 * h + q] = *(const f32x4*)(p.w8_scale + nb + 32 * h + 4 * q);
+#endif
       }
     float sa[A8 ? MT : 1];                          // A8: the frame rows' scales
     if (A8) {
@@ -348,8 +354,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       const long r = orow[u] >= 0 ? orow[u] : p.c_lead;     // any valid row: the value is never stored
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+#ifdef WFL_ABL_EPI_NOLOAD
+        rr[slot][h] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; rl[slot][h] = rr[slot][h]; (void)r;
+#else
         rr[slot][h] = *(const bf16x8*)(p.res + r * p.ldres + nb + 32 * h);
         rl[slot][h] = *(const bf16x8*)(res_lo + r * p.ldres + nb + 32 * h);
+#endif
       }
     };
     if (RES) {
