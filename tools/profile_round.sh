@@ -18,6 +18,10 @@ timeout -k 10 300 $B --full-head --batch 64 --steps 12 --warmup 3 --no-cpu-basel
 timeout -k 10 300 $B --config-index 2 --steps 6 --warmup 2 --cpu-clips 2 --cpu-calls 3 > $OUT/bench_cfg3.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 $B --config-index 3 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg4.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 $B --config-index 4 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_fp8.json 2>> $OUT/bench.err || exit 1
+# round 4: the activation formats of the fp8 config beside its default (bf16 activations), same box
+for act in fp8 fp8_pair fp8_nonscaled; do
+  timeout -k 10 300 $B --config-index 4 --activation-dtype $act --steps 6 --warmup 2 --no-cpu-baseline --no-h2d > $OUT/bench_cfg5_act_$act.json 2>> $OUT/bench.err || exit 1
+done
 timeout -k 10 300 $B --precision high --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg2_precision_high.json 2>> $OUT/bench.err || exit 1
 WFL_BENCH_FAKE_WORLD=1 timeout -k 10 200 $B --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-h2d > $OUT/bench_fake_world.json 2>> $OUT/bench.err || exit 1
 echo "== kernel stats"
@@ -26,6 +30,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2 -o cfg2_inflight2 -- $B $P --inflight 2 > $OUT/ks2.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf -o fullhead_inflight1 -- $B $P --inflight 1 --full-head > $OUT/ksf.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks5 -o cfg5_inflight1 -- $B --steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --config-index 4 > $OUT/ks5.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks5a -o cfg5_act_fp8_inflight1 -- $B --steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --config-index 4 --activation-dtype fp8 > $OUT/ks5a.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksh -o cfg2_precision_high -- $B --steps 6 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --precision high > $OUT/ksh.log 2>&1 || exit 1
 fi
 if [ $PART = a ]; then echo done; exit 0; fi

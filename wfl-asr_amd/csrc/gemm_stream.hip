@@ -515,10 +515,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const uint2 raw = *(const uint2*)(sb + w_off[v]);
-        typedef __attribute__((ext_vector_type(2))) float f32x2_;
-        const f32x2_ a = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.x, true);
-        const f32x2_ c2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, false), d2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw.y, true);
-        fw[v] = (bf16x8){(bf16_t)a[0], (bf16_t)a[1], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)c2[0], (bf16_t)c2[1], (bf16_t)d2[0], (bf16_t)d2[1]};
+        // e4m3 -> bf16, two values per instruction (v_cvt_scalef32_pk_bf16_fp8, scale 1: exact -- round 4; rounds 2-3 went through fp32
+        // with v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32, twice the instructions in the L slot that bounds this kernel's K step)
+        const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, true);
+        const bf16x2 c2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, false), d2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, true);
+        fw[v] = (bf16x8){a[0], a[1], b[0], b[1], c2[0], c2[1], d2[0], d2[1]};
       }
     } else {
 #pragma unroll
