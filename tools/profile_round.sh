@@ -25,7 +25,7 @@ done
 timeout -k 10 300 $B --precision high --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg2_precision_high.json 2>> $OUT/bench.err || exit 1
 WFL_BENCH_FAKE_WORLD=1 timeout -k 10 200 $B --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-h2d > $OUT/bench_fake_world.json 2>> $OUT/bench.err || exit 1
 echo "== kernel stats"
-P="--steps 10 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d"
+P="--steps 10 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d --no-precision-high"     # (one model per profile: the precision-high leg has its own run)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks1 -o cfg2_inflight1 -- $B $P --inflight 1 > $OUT/ks1.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2 -o cfg2_inflight2 -- $B $P --inflight 2 > $OUT/ks2.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ksf -o fullhead_inflight1 -- $B $P --inflight 1 --full-head > $OUT/ksf.log 2>&1 || exit 1
@@ -35,7 +35,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 fi
 if [ $PART = a ]; then echo done; exit 0; fi
 echo "== pmc"
-P4="--steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1"
+P="--steps 10 --warmup 2 --no-kernel-events --no-cpu-baseline --no-h2d --no-precision-high"
+if [ $PART = b ]; then
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks1 -o cfg2_inflight1 -- $B $P --inflight 1 > $OUT/ks1.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks2 -o cfg2_inflight2 -- $B $P --inflight 2 > $OUT/ks2.log 2>&1 || exit 1
+fi
+P4="--steps 4 --warmup 1 --no-kernel-events --no-cpu-baseline --no-h2d --inflight 1 --no-precision-high"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B $P4 > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $B $P4 > $OUT/pmc_write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B $P4 > $OUT/pmc_sq.log 2>&1 || exit 1
