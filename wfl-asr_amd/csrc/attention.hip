@@ -546,6 +546,7 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
 }
 
 int wfl_launch_attention_big(const AttnArgs& a, hipStream_t s);   // attention_big.hip: head_dim 384 / 512 / 640
+int wfl_launch_attention_pp(const AttnArgs& a, hipStream_t s);    // attention_pp.hip (round 4): head_dim 64 as an eight-wave ping-pong; 1 = not taken
 
 // WFL_ATTN_VARIANT=1 selects round 1's kernel (attention_big.hip) for head_dim 384 (A/B runs)
 static int attn_variant() {
@@ -557,6 +558,10 @@ static int attn_variant() {
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldv % 8 || a.ldo % 4 || a.T <= 0 || !a.V) return -1;
   const int hd = a.d / a.heads;
+  if (hd == 64 && !a.bias && !(a.QK_lo && a.V_lo)) {
+    const int r = wfl_launch_attention_pp(a, s);
+    if (r != 1) return r;
+  }
   if (a.O8) {
     if (a.bias || hd != 64 || a.ldo8 % 4) return -4;
     return launch_attn<64, 2, true, false, true>(a, s);
