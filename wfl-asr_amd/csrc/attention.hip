@@ -67,7 +67,10 @@ template <int HD, int QT, bool PREFETCH, bool BIAS, bool OUT8 = false, bool SPLI
 //  spilled, 93 against 91 at 129 registers / 5 spilled: a fourth workgroup per CU adds more LDS and L2 contention than latency hiding.
 //  A software-pipelined loop -- the scores of tile kt + 1 issued before the softmax of tile kt, K staged one tile ahead of V -- was built
 //  and removed again: hipcc wants 218 registers for it (two waves per SIMD: 106.5 us against 94.0 on the same box), and capped at
-//  three waves per SIMD it spills 66-86 of them.)
+//  three waves per SIMD it spills 66-86 of them.
+//  Round 4: an eight-wave workgroup whose two wave groups alternate between the matrix pipe and the softmax / fragment reads, barriers
+//  between the phases (attention_pp.hip in the history), was built, equal in output, and 17-30 % SLOWER: one wave per SIMD issuing
+//  v_mfma_f32_16x16x32 leaves the other wave 8 of every 16 issue cycles, its softmax needs more -- profiles/round4_attn_pp_dead_end.txt.)
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   static_assert(!SPLIT || !OUT8, "split precision: bf16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -546,7 +549,6 @@ static int launch_attn(const AttnArgs& a, hipStream_t s) {
 }
 
 int wfl_launch_attention_big(const AttnArgs& a, hipStream_t s);   // attention_big.hip: head_dim 384 / 512 / 640
-int wfl_launch_attention_pp(const AttnArgs& a, hipStream_t s);    // attention_pp.hip (round 4): head_dim 64 as an eight-wave ping-pong; 1 = not taken
 
 // WFL_ATTN_VARIANT=1 selects round 1's kernel (attention_big.hip) for head_dim 384 (A/B runs)
 static int attn_variant() {
@@ -558,10 +560,6 @@ static int attn_variant() {
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.heads <= 0 || a.d % a.heads || a.P % 8 || a.ldqk % 8 || a.ldv % 8 || a.ldo % 4 || a.T <= 0 || !a.V) return -1;
   const int hd = a.d / a.heads;
-  if (hd == 64 && !a.bias && !(a.QK_lo && a.V_lo)) {
-    const int r = wfl_launch_attention_pp(a, s);
-    if (r != 1) return r;
-  }
   if (a.O8) {
     if (a.bias || hd != 64 || a.ldo8 % 4) return -4;
     return launch_attn<64, 2, true, false, true>(a, s);
