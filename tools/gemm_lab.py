@@ -80,7 +80,7 @@ def main():
         lo_mode = bool(os.environ.get("LAB_LO")) and res            # residual stream as hi + lo (+ statistics with LAB_STATS)
         Rlo = (torch.randn(R, N, device="cuda") * 0.003).to(torch.bfloat16) if lo_mode else None
         Clo = torch.zeros(R, N, dtype=torch.bfloat16, device="cuda") if lo_mode else None
-        Sts = torch.zeros(R * 16, dtype=torch.float32, device="cuda") if (res and os.environ.get("LAB_STATS") and N <= 1024) else None
+        Sts = torch.zeros(R * 8, dtype=torch.float32, device="cuda") if (res and os.environ.get("LAB_STATS") and N <= 1024) else None
         bias = torch.randn(N, device="cuda")
         stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

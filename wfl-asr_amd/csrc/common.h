@@ -83,7 +83,7 @@ struct GemmArgs {
   const float* ln_s;        // LayerNorm folded in front of the GEMM (gemm_stream.hip): s[n] = sum_k W'[n][k], W' = gamma o W,
   float ln_eps;             //   bias = b + W beta;  out = rstd_m * (acc - mean_m * s[n]) + bias[n];  statistics over the K columns
   float* stats_out;         // residual launches (gemm_stream.hip): per output row, per 256-column tile, (sum, sum of squares) of
-                            //   the bf16-rounded outputs: stats_out[(row * 8 + tile) * 2 + {0, 1}], row = the C row index, N <= 2048
+                            //   the bf16-rounded outputs: stats_out[(row * 4 + tile) * 2 + {0, 1}], row = the C row index, N <= 1024
   const float* stats_in;    // with ln_s: take the row statistics from a producer's stats_out (row = A row m + stats_lead)
   int stats_nsl;            //   instead of summing the fragments in the kernel; stats_nsl = tiles per row (producer's N / 256)
   long stats_lead;

@@ -99,8 +99,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   constexpr int AOFF = SNST * STB;
   constexpr int NSTORE = (RES ? 4 : 2) * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around; a residual
                                                                   // launch always stores the hi and the lo half)
-  constexpr int SROW = 8;                             // float2 slots per row of the statistics buffer (one per 256-column tile: widths up to 2048;
-                                                      //   round 4: 4 -> 8, so that Whisper-large's d = 1280 folds its LayerNorms too)
+  constexpr int SROW = 4;                             // float2 slots per row of the statistics buffer (one per 256-column tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* stat_lds = (float*)(smem + SNST * STB + (CONV ? 2 * AEXT : 0));  // LNF == 1: [2 groups][MT*16 rows][2]; STATS: [2][4 waves][MT*16][2] + 2 counters
   const int tid = threadIdx.x;
@@ -388,36 +387,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         sp[u][0] = q[0];
         sp[u][1] = q[1];
       }
-      float a1[MT], a2[MT];
 #pragma unroll
       for (int u = 0; u < MT; ++u) {
-        a1[u] = sp[u][0][0]; a2[u] = sp[u][0][1];
-        if (p.stats_nsl > 1) { a1[u] += sp[u][0][2]; a2[u] += sp[u][0][3]; }
-        if (p.stats_nsl > 2) { a1[u] += sp[u][1][0]; a2[u] += sp[u][1][1]; }
-        if (p.stats_nsl > 3) { a1[u] += sp[u][1][2]; a2[u] += sp[u][1][3]; }
-      }
-      if (p.stats_nsl > 4) {                         // (wave-uniform) slots 4 .. 7 in a second batch through the same registers
-#pragma unroll
-        for (int u = 0; u < MT; ++u) {
-          int m = mrow0 + 16 * u;
-          m = m < p.M ? m : p.M - 1;
-          const f32x4* q = (const f32x4*)(p.stats_in + (p.stats_lead + m) * (2 * SROW));
-          sp[u][0] = q[2];
-          sp[u][1] = q[3];
-        }
-#pragma unroll
-        for (int u = 0; u < MT; ++u) {
-          a1[u] += sp[u][0][0]; a2[u] += sp[u][0][1];
-          if (p.stats_nsl > 5) { a1[u] += sp[u][0][2]; a2[u] += sp[u][0][3]; }
-          if (p.stats_nsl > 6) { a1[u] += sp[u][1][0]; a2[u] += sp[u][1][1]; }
-          if (p.stats_nsl > 7) { a1[u] += sp[u][1][2]; a2[u] += sp[u][1][3]; }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < MT; ++u) {
-        const float mean = a1[u] / (float)p.K;
+        float a1 = sp[u][0][0], a2 = sp[u][0][1];
+        if (p.stats_nsl > 1) { a1 += sp[u][0][2]; a2 += sp[u][0][3]; }
+        if (p.stats_nsl > 2) { a1 += sp[u][1][0]; a2 += sp[u][1][1]; }
+        if (p.stats_nsl > 3) { a1 += sp[u][1][2]; a2 += sp[u][1][3]; }
+        const float mean = a1 / (float)p.K;
         mu[u] = mean;
-        rs[u] = rsqrtf(fmaxf(a2[u] / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+        rs[u] = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
       }
     }
     char* trash = (char*)p.trash + lane * 16;
@@ -752,8 +730,8 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   if (a.N % 256 || a.K % SBK || a.cin % SBK || a.K / SBK < 8 || a.n_valid % 8) return false;
   // (no lower bound on M: a LayerNorm folded through the producer's statistics must not depend on the batch size -- a clip
   // labelled alone has to equal the same clip inside a batch bit for bit)
-  if (a.stats_out && (!a.res || a.N / 256 > 8)) return false;          // 8 tile slots per row of the statistics buffer
-  if (a.stats_in && (!a.ln_s || a.stats_nsl <= 0 || a.stats_nsl > 8)) return false;
+  if (a.stats_out && (!a.res || a.N / 256 > 4)) return false;          // 4 tile slots per row of the statistics buffer
+  if (a.stats_in && (!a.ln_s || a.stats_nsl <= 0 || a.stats_nsl > 4)) return false;
   if (a.res && a.act != WFL_ACT_NONE) return false;
   if (a.ln_s && (a.res || a.cin < a.K || (a.act != WFL_ACT_NONE && a.act != WFL_ACT_GELU))) return false;
   if (a.act == WFL_ACT_SIGMOID) return false;

@@ -1145,7 +1145,7 @@ static Plan make_plan(const wfl_model* m, int B, int L, int T_frames = 0) {
     p.X8lo = take(p.R * (long)p.d);
     p.FF8lo = take(p.R * (long)p.ffw);
   }
-  p.stats = take(p.R * 8L * 2 * 4);                     // per row, per 256-column tile (<= 8): (sum, sum of squares)
+  p.stats = take(p.R * 4L * 2 * 4);                     // per row, per 256-column tile (<= 4): (sum, sum of squares)
   p.enc2 = take(p.R * p.d * 2);
   p.clipmax = take((long)B * 4);
   p.logits = take((long)B * p.T * round_up(a.num_classes, 4) * 4);      // (rows of a multiple of four floats when the caller does not ask for them)
