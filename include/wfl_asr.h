@@ -194,6 +194,25 @@ int32_t wfl_op_gemm_ln(const void* A, int64_t lda, const void* W, int32_t M, int
 int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* V, int64_t ldv, void* O, int64_t ldo, int32_t B,
                          int32_t T, int32_t P, int32_t heads, int32_t d, void* stream);
 
+/* fp8 x fp8 GEMM on the block-scaled MFMA (csrc/gemm_mx.hip, round 4; the encoder GEMMs of an fp8-weight model, HF modeling_whisper.py:
+ * 309-354, 391-407 via /root/reference/model.py:155-156):
+ *   C[row(b,t)][n] = res + alpha * act( w_scale[n] * sa(m) * sum_k a(m, k) W8[n][k] + bias[n] )
+ * W8 [N][K] OCP e4m3 bytes; a(m, k) = A8[m][k] (e4m3 bytes, lda bytes per row), or A8[m][k] + A8_lo[m][k] / 16 when A8_lo is given
+ * (an e4m3 PAIR: lo = e4m3(16 (x / sa - hi))); sa(m) = a_scale[m] or a_static when a_scale is null.  N % 256 == 0, K % 128 == 0, K >= 512.
+ * res / res_lo / c_lo are bf16 rows with C's leading dimension and row mapping.
+ * Output: bf16 rows C (+ the low half c_lo with a residual), or -- c8 given -- e4m3(out * c8_inv_scale) into c8 and, c8_lo given, the
+ * remainder e4m3(16 (out * c8_inv_scale - hi)) into c8_lo (ldc8 bytes per row); an e4m3 store that saturates ORs 2 into *status. */
+int32_t wfl_op_gemm_mx(const void* A8, const void* A8_lo, int64_t lda, const void* W8, const float* w_scale, const float* a_scale,
+                       float a_static, int32_t M, int32_t N, int32_t K, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead,
+                       int32_t c_pitch, const float* bias, const void* res, const void* res_lo, void* c_lo, float alpha, int32_t act,
+                       void* c8, void* c8_lo, int64_t ldc8, float c8_inv_scale, int32_t* status, void* stream);
+
+/* Frame rows -> e4m3 with one fp32 scale per row (row maximum -> 448), optionally LayerNorm(gamma, beta, eps) first (gamma null: plain
+ * quantisation) and optionally as a PAIR (y8_lo given: e4m3(16 (x / scale - hi))): the producers of gemm_mx's frame operand
+ * (csrc/norm.hip rows_fp8_kernel; HF modeling_whisper.py:384, 399).  x (+ x_lo when given) are bf16 rows, C % 8 == 0, C <= 2048. */
+int32_t wfl_op_rows_fp8(const void* x, int64_t ldx, const void* x_lo, const float* gamma, const float* beta, float eps, int64_t lead,
+                        int32_t B, int32_t P, int32_t T, int32_t C, void* y8, void* y8_lo, int64_t ldy8, float* scale, void* stream);
+
 int32_t wfl_op_layernorm(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                          float eps, int64_t lead, int32_t B, int32_t P, int32_t T, int32_t C, void* stream);
 

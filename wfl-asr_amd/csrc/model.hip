@@ -2190,6 +2190,28 @@ int32_t wfl_check(wfl_model* m, void* workspace, int64_t workspace_bytes, int32_
 }
 
 // ------------------------------------------------------------------------------------------------ single-op exports
+int32_t wfl_op_gemm_mx(const void* A8, const void* A8_lo, int64_t lda, const void* W8, const float* w_scale, const float* a_scale,
+                       float a_static, int32_t M, int32_t N, int32_t K, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead,
+                       int32_t c_pitch, const float* bias, const void* res, const void* res_lo, void* c_lo, float alpha, int32_t act,
+                       void* c8, void* c8_lo, int64_t ldc8, float c8_inv_scale, int32_t* status, void* stream) {
+  GemmArgs g{};
+  g.A = (const bf16_t*)A8; g.a8_lo = (const unsigned char*)A8_lo; g.a8 = A8_lo ? 3 : 2; g.lda = lda; g.cin = K; g.W = (const bf16_t*)W8;
+  g.w8_scale = w_scale; g.a8_scale = a_scale; g.a8_static = a_static; g.a8_lead = 0;
+  g.M = M; g.N = N; g.K = K; g.n_valid = N; g.P = P; g.T = T; g.C = C; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch;
+  g.bias = bias; g.res = (const bf16_t*)res; g.res_lo = (const bf16_t*)res_lo; g.c_lo = (bf16_t*)c_lo; g.ldres = ldc; g.alpha = alpha; g.act = act;
+  g.c8 = (unsigned char*)c8; g.c8_lo = (unsigned char*)c8_lo; g.ldc8 = ldc8; g.c8_inv_scale = c8_inv_scale; g.err = (unsigned*)status;
+  if (!A8 || !W8 || !w_scale || (!C && !c8) || M <= 0 || P <= 0 || P % 8) return fail(-1, "wfl_op_gemm_mx: bad argument");
+  const int r = wfl_launch_gemm_mx(g, (hipStream_t)stream);
+  return r ? fail(r == 1 ? -1 : r, "wfl_op_gemm_mx: shape or argument not taken by gemm_mx.hip (" + std::to_string(r) + ")") : 0;
+}
+
+int32_t wfl_op_rows_fp8(const void* x, int64_t ldx, const void* x_lo, const float* gamma, const float* beta, float eps, int64_t lead,
+                        int32_t B, int32_t P, int32_t T, int32_t C, void* y8, void* y8_lo, int64_t ldy8, float* scale, void* stream) {
+  const int r = wfl_launch_rows_fp8((const bf16_t*)x, ldx, (const bf16_t*)x_lo, gamma, beta, eps, lead, B, P, T, C, (unsigned char*)y8, ldy8,
+                                    scale, (hipStream_t)stream, (unsigned char*)y8_lo);
+  return r ? fail(r, "wfl_op_rows_fp8: invalid arguments or launch failure") : 0;
+}
+
 int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride, const void* W, int32_t M, int32_t N,
                     int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, int64_t ldc, int64_t c_lead, int32_t c_pitch,
                     const float* bias, const void* res, int64_t ldres, float alpha, int32_t act, int32_t glu,
