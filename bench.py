@@ -216,7 +216,7 @@ def cpu_model() -> str:
 def cpu_baseline(cfg, labels, sd_np, clips, calls, clip_seconds):
     """The oracle forward on host cores.  Only this leg (and tests / smoke) may touch oracle/."""
     from oracle import wfl_oracle as O
-    from wfl_asr_amd import synth
+    import synthetic as synth
     from wfl_asr_amd.archs import resolve_encoder_arch
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -280,7 +280,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from wfl_asr_amd import synth
+    import synthetic as synth
     from wfl_asr_amd.tagger import BIOPhonemeTagger, raise_on_status
     from wfl_asr_amd.dist import gather_packed
 

@@ -1,4 +1,5 @@
-"""Deterministic synthetic checkpoints and clips (no files ship, no torch RNG).
+"""Deterministic synthetic checkpoints and clips (no files ship, no torch RNG).  TEST / BENCH INFRASTRUCTURE, not product: it lives outside
+the `wfl-asr_amd/` package (round 4; it used to be `wfl_asr_amd.synth`) and is imported by bench.py, tests/, tools/ and __graft_entry__.smoke().
 
 There is no network here, so no pretrained/fine-tuned weights exist in this pipeline
 (SURVEY.md §8c).  Benchmarks, golden fixtures and GPU parity tests therefore all run on a
@@ -13,7 +14,8 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .archs import WhisperArch, WavLMArch, head_config, resolve_encoder_arch  # noqa: F401 (head_config re-exported)
+import wfl_asr_amd  # noqa: F401  (registers the package from ./wfl-asr_amd)
+from wfl_asr_amd.archs import WhisperArch, WavLMArch, head_config, resolve_encoder_arch  # noqa: F401 (head_config re-exported)
 
 _M64 = (1 << 64) - 1
 

@@ -1,5 +1,5 @@
 """Configs of the golden cases (must match tests/golden/make_golden.py)."""
-from wfl_asr_amd import synth
+import synthetic as synth
 
 
 def tiny_whisper_config(**kw):

@@ -6,7 +6,7 @@ tests/bench/smoke imports this file).  Recipe from SURVEY.md §8c: import the HF
 stub the absent `torchaudio` / `soundfile` modules (untouched on the Whisper/WavLM inference
 path), put /root/reference on sys.path, build the reference's unmodified `BIOPhonemeTagger`
 from a *local* HF directory (random init; no hub access), load the deterministic synthetic
-state dict from `wfl_asr_amd.synth` strictly, and record its outputs on the synthetic clips.
+state dict from `synthetic` strictly, and record its outputs on the synthetic clips.
 
 Outputs (all small):
   whisper_tiny.npz        full tensors for a d=64 / 2-layer / 100-frame Whisper + full default head
@@ -52,7 +52,7 @@ import utils as ref_utils      # noqa: E402
 import infer as ref_infer      # noqa: E402
 from scipy.ndimage import median_filter  # noqa: E402
 
-from wfl_asr_amd import synth  # noqa: E402
+import synthetic as synth  # noqa: E402
 from wfl_asr_amd.archs import resolve_encoder_arch  # noqa: E402
 
 torch.manual_seed(0)

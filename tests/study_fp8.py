@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wfl_oracle as O   # noqa: E402
-from wfl_asr_amd import synth   # noqa: E402
+import synthetic as synth   # noqa: E402
 from wfl_asr_amd.archs import resolve_encoder_arch   # noqa: E402
 
 

@@ -84,6 +84,8 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                # nor the generator of synthetic checkpoints / clips (round 4: synthetic/ is test and bench infrastructure)
+                assert not re.search(r"^\s*(from|import)\s+synthetic\b", txt, flags=re.M), f
 
 
 def test_no_object_holds_the_packed_f32_form_that_fails_beside_mfma_waves(libpath, tmp_path):
@@ -111,7 +113,7 @@ def test_no_object_holds_the_packed_f32_form_that_fails_beside_mfma_waves(libpat
 def test_precision_high_refuses_fp8_weights(libpath):
     """`model.precision: high` with `model.weight_dtype: fp8` is a contradiction the constructor names (no GPU needed)."""
     import pytest
-    from wfl_asr_amd import synth
+    import synthetic as synth
     from wfl_asr_amd.tagger import BIOPhonemeTagger
     cfg = synth.baseline_config(4)
     cfg["model"]["precision"] = "high"
@@ -126,7 +128,7 @@ def test_precision_high_and_activation_formats_are_validated(libpath):
     H = 512, cfg4's H = 384).  Round 4 built the three-pass recurrence for them (csrc/lstm.hip, the four-wave form); what is left to refuse
     is a hidden size beyond 640, and the constructor says what it built."""
     import pytest
-    from wfl_asr_amd import synth
+    import synthetic as synth
     from wfl_asr_amd.tagger import BIOPhonemeTagger
     labels = synth.make_labels(5)
     cfg = synth.baseline_config(3)                      # Whisper-small + full head: BiLSTM hidden 384

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from wfl_asr_amd import correct_label as CL
-from wfl_asr_amd import synth
+import synthetic as synth
 
 pytestmark = pytest.mark.gpu
 

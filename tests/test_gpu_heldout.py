@@ -19,7 +19,7 @@ import torch
 from oracle import wfl_oracle as O
 from wfl_asr_amd import infer as I
 from wfl_asr_amd import postprocess as pp
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.archs import resolve_encoder_arch
 from test_gpu_model import TAU, BAND, TAU_W, BAND_W, _note
 

@@ -14,7 +14,7 @@ import yaml
 from wfl_asr_amd import _lib
 from wfl_asr_amd import audio as A
 from wfl_asr_amd import infer as I
-from wfl_asr_amd import synth
+import synthetic as synth
 from cases import tiny_whisper_config
 
 pytestmark = pytest.mark.gpu

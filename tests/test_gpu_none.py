@@ -16,7 +16,7 @@ import yaml
 from oracle import wfl_oracle as O
 from wfl_asr_amd import audio as A
 from wfl_asr_amd import infer as I
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.archs import resolve_encoder_arch
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 

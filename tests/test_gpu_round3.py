@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import wfl_oracle as O
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.archs import resolve_encoder_arch
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 from cases import GOLDEN_CASES, tiny_whisper_config, tiny_wavlm_config

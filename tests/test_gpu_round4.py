@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import wfl_oracle as O
-from wfl_asr_amd import synth
+import synthetic as synth
 from test_gpu_model import _build, _note, _oracle
 
 pytestmark = pytest.mark.gpu

@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from oracle import wfl_oracle as O
-from wfl_asr_amd import _lib, synth
+from wfl_asr_amd import _lib
+import synthetic as synth
 from wfl_asr_amd.archs import MelArch, resolve_encoder_arch
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 

@@ -2,7 +2,7 @@
 workgroup, in-loop statistics epilogues) must be bit-identical.  tests/test_gpu_model.py checks the same at the benchmark batch."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 cfg = synth.baseline_config(1)
 labels = synth.make_labels(70)

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 from cases import tiny_whisper_config
 

@@ -19,7 +19,7 @@ from wfl_asr_amd import audio as A
 from wfl_asr_amd import infer as I
 from wfl_asr_amd import native_post as npost
 from wfl_asr_amd import postprocess as pp
-from wfl_asr_amd import synth
+import synthetic as synth
 
 
 def main():

@@ -16,7 +16,7 @@ import torch
 
 from wfl_asr_amd import audio as A
 from wfl_asr_amd import infer as I
-from wfl_asr_amd import synth
+import synthetic as synth
 
 
 def main():

@@ -9,7 +9,7 @@ usage: repro_wavlm_two_streams.py"""
 import os, sys, dataclasses
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.archs import WAVLM
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 def build(cfg, seed=1, nph=70):

@@ -5,7 +5,8 @@ results.  Round 2: 0 of 720 differ.  usage: soak_two_streams.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from wfl_asr_amd import synth, _lib
+from wfl_asr_amd import _lib
+import synthetic as synth
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 lib = _lib.load()
 def build(cfg, seed=1):

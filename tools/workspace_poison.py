@@ -6,7 +6,7 @@ import os, sys
 ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from wfl_asr_amd import synth
+import synthetic as synth
 from wfl_asr_amd.tagger import BIOPhonemeTagger
 from cases import tiny_whisper_config, tiny_wavlm_config
 def run(name, cfg, L, B, lens=None):
