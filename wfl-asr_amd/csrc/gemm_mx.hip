@@ -40,6 +40,9 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define MXNCU 256
+#ifndef MX_DMA_IN_C
+#define MX_DMA_IN_C 1     // the operand DMA of stage s + 2 is issued from the C slot, among the MFMAs (0: from the L slot, among the ds_reads: 11-17 % slower, profiles/round4_mx_lab_dma_in_c.txt)
+#endif
 
 // Diagnostic build (tools/mx_lab.py, -DWFL_GEMM_STAMPS): per workgroup and wave group, cycles (s_memtime) spent in the prologue, the
 // epilogues, the DMA waits, the barriers and the MFMA issue, written to GemmArgs::stamps[block][group][8] by one lane of each group.
@@ -354,7 +357,9 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
         const i32x4 lo = *(const i32x4*)(sb + x_off[0] + u * 2048), hi = *(const i32x4*)(sb + x_off[1] + u * 2048);
         fx[u] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+#if !MX_DMA_IN_C
       prefetch_one();
+#endif
       const bool stores = have_prev && kt < R - 2;    // the epilogue's stores are younger than the stage awaited next
       MXACC(st_l, tq); tq = MXT();
       if (grp) wait_stage(s + 1, stores);             // group 1 waits before the barrier ...
@@ -366,10 +371,14 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
       // ---- C slot
 #ifndef MX_ABL_NOMMA
 #pragma unroll
-      for (int u = 0; u < MT; ++u)
+      for (int u = 0; u < MT; ++u) {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
           acc[u][v] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[v], fx[u], acc[u][v], 0, 0, 0, scale_w, 0, scale_x);
+#if MX_DMA_IN_C
+        if (u == 0) prefetch_one();                  // the DMA of stage s + 2 among the MFMAs: an LDS-DMA instruction issued here costs a third
+#endif                                               //   of one issued among the L slot's ds_reads; in one clump - spread over the slot it loses 2-7 %
+      }
 #else
       acc[0][0][0] += (float)fw[0][0] + (float)fx[0][0];
 #endif
