@@ -472,11 +472,18 @@ def main():
             acts = {0: 0, 1: 1, 2: 2, 3: 3}
             fp8_act = str(m.get("weight_dtype", "bf16")) == "fp8" and os.environ.get("WFL_FP8_ACT", "0" if m.get("activation_dtype", "bf16") == "bf16" else "1") != "0"
 
+            mx_act = {"fp8": "single", "e4m3": "single", "float8_e4m3fn": "single", "fp8_pair": "pair", "e4m3_pair": "pair"}.get(
+                str(m.get("activation_dtype", "bf16")))
+
             def kname(key):
                 """rocprofv3 kernel name of the template instantiation behind a profile key (model.hip: Runner::gemm)."""
                 act, glu, f32, res, kid = key & 3, bool(key & 4), bool(key & 8), bool(key & 16), (key >> 5) & 7
                 lnf, stats = (key >> 8) & 3, bool(key & 1024)
                 tf = lambda b: "true" if b else "false"
+                if kid == 7 and fp8_act and mx_act:   # both operands e4m3 on the block-scaled MFMA (gemm_mx.hip): <ACT, MT, RES, PAIR, OUT>
+                    pair = mx_act == "pair"
+                    return "gemm_mx_kernel<%d, %d, %s, %s, %d>" % (acts[act], 6 if pair else 5, tf(res), tf(pair),
+                                                                    (2 if pair else 1) if (act == 1 and not res) else 0)
                 if kid in (1, 5, 6, 7):               # 6 = the tap-stationary conv mode, 7 = fp8: e4m3 weights (W8) or both operands e4m3 (A8)
                     a8 = kid == 7 and fp8_act
                     return "gemm_stream_kernel<%d, %d, %s, %d, %s, %s, %s, %s, %s>" % (
@@ -501,7 +508,7 @@ def main():
                 breakdown[OTHER_KEYS.get(p["key"], str(p["key"]))] = p["ms"] / args.steps
             roof = {
                 "bound": "mfma",
-                "kernel": "MFMA GEMM family (gemm_stream_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations)"
+                "kernel": "MFMA GEMM family (gemm_stream_kernel / gemm_mx_kernel / gemm256_kernel / gemm_bf16_kernel, all instantiations)"
                           + ("; fp8 model: every launch priced against the 5 PF dense fp8 roof" if is_fp8 else "; bf16, 2.5 PF dense roof"),
                 "timing": "HIP events (launch stream) around every launch of a second pass over the same %d steps, run right after the "
                           "timed region, one batch at a time so that no other kernel shares the GPU with the one being timed "

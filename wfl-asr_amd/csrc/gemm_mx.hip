@@ -40,6 +40,9 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define MXNCU 256
+#ifndef MX_EPI_G1_EARLY
+#define MX_EPI_G1_EARLY 1  // group 1's epilogue right behind its tile's last MFMAs (kernels without a residual): profiles/round4_mx_lab_epilogue_overlap.txt
+#endif
 #ifndef MX_DMA_IN_C
 #define MX_DMA_IN_C 1     // the operand DMA of stage s + 2 is issued from the C slot, among the MFMAs (0: from the L slot, among the ds_reads: 11-17 % slower, profiles/round4_mx_lab_dma_in_c.txt)
 #endif
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
   const long long st_t1 = MXT();
 
 #define MSB() __builtin_amdgcn_sched_barrier(0)
+  constexpr bool EARLY1 = MX_EPI_G1_EARLY && !RES;
   i32x8 fw[4], fx[MT];
   int s = 0, rslot = 0;
   int pm0 = 0, pn0 = 0;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
       // ---- L slot (the other group issues its MFMAs meanwhile): the previous tile's epilogue, this stage's fragments, the DMA of stage s + 2
       long long tq = MXT();
-      if (kt == 0 && have_prev) { epilogue(pm0, pn0); MXACC(st_ep, tq); tq = MXT(); }
+      if (kt == 0 && have_prev && !(EARLY1 && grp)) { epilogue(pm0, pn0); MXACC(st_ep, tq); tq = MXT(); }
       const char* sb = smem + rslot * STB;
 #ifdef MX_ABL_NOLDS
       if (s == 0)
@@ -384,6 +388,11 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
 #endif
       MSB();
       MXACC(st_mma, tq); tq = MXT();
+      // group 1 stores its tile right behind the tile's last MFMAs, i.e. in the same barrier interval in which group 0 (one barrier ahead) runs
+      // ITS epilogue at the head of the next tile's first L slot: the two epilogues overlap instead of following each other.  (Same order in
+      // the wave's vmcnt queue as before: the DMA issued in this step, the stores, the DMA of the next step.)
+      // (Not for the residual epilogues: those are bound by their HBM bytes, two at once gain nothing: measured -2 ... +3 %; the others +3 ... +8 %.)
+      if (EARLY1 && grp && kt == nk - 1) { epilogue(m0, n0); MXACC(st_ep, tq); tq = MXT(); }
       if (!grp) wait_stage(s + 1, stores);            // ... group 0 after its MFMAs
       MXACC(st_wait, tq); tq = MXT();
       if (!(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
   }
   {
     const long long tq = MXT();
-    if (have_prev) epilogue(pm0, pn0);
+    if (have_prev && !(EARLY1 && grp)) epilogue(pm0, pn0);
     MXACC(st_ep, tq);
   }
 #ifdef WFL_GEMM_STAMPS
