@@ -18,12 +18,12 @@ DRV = '''
 #include "common.h"
 extern "C" int diag_gemm(const void* A, long lda, int cin, long tap_stride, const void* W, int M, int N, int K, int P, int T,
                          void* Cout, long ldc, long c_lead, const float* bias, const void* res, int act, unsigned long long* stamps,
-                         const float* ln_s, void* stream, const void* res_lo, void* c_lo, float* stats_out) {
+                         const float* ln_s, void* stream, const void* res_lo, void* c_lo, float* stats_out, const float* w8_scale) {
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.lda = lda; g.cin = cin > 0 ? cin : K; g.tap_stride = tap_stride; g.W = (const bf16_t*)W;
   g.M = M; g.N = N; g.K = K; g.n_valid = N; g.P = P; g.T = T; g.C = Cout; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = P;
   g.bias = bias; g.res = (const bf16_t*)res; g.ldres = ldc; g.alpha = 1.f; g.act = act; g.stamps = stamps; g.ln_s = ln_s; g.ln_eps = 1e-5f;
-  g.res_lo = (const bf16_t*)res_lo; g.c_lo = (bf16_t*)c_lo; g.stats_out = stats_out;
+  g.res_lo = (const bf16_t*)res_lo; g.c_lo = (bf16_t*)c_lo; g.stats_out = stats_out; g.w8_scale = w8_scale;
   return wfl_launch_gemm(g, (hipStream_t)stream);
 }
 '''
@@ -63,16 +63,19 @@ def main():
         lib = C.CDLL(path)
         lib.diag_gemm.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p]
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         libs[name] = lib
-    B, T, P, lead = 16, 1500, 1520, 16
+    B, T, P, lead = (32 if os.environ.get("LAB_CFG5") else 16), 1500, 1520, 16
+    w8 = bool(os.environ.get("LAB_W8"))                # e4m3 weights + per-channel scales (gemm_stream's W8 instantiations)
     M = B * P
     R = lead + M + 256
     only = os.environ.get("LAB_SHAPES")
-    for name, K, N, act, res in SHAPES:
+    shapes = SHAPES if not os.environ.get("LAB_CFG5") else [("qkv", 1280, 3840, 0, False), ("out+res", 1280, 1280, 0, True),
+                                                            ("fc1 gelu", 1280, 5120, 1, False), ("fc2+res", 5120, 1280, 0, True)]
+    for name, K, N, act, res in shapes:
         if only and name.split()[0] not in only.split(","):
             continue
-        kin = min(K, 2048)
+        kin = K if os.environ.get("LAB_CFG5") else min(K, 2048)
         A = (torch.randn(R + 64, kin, device="cuda") * 0.5).to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         Cb = torch.zeros(R, N, dtype=torch.bfloat16, device="cuda")
@@ -84,20 +87,25 @@ def main():
         bias = torch.randn(N, device="cuda")
         stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        lda = kin if K <= 2048 else 512
+        lda = kin if (K <= 2048 or os.environ.get("LAB_CFG5")) else 512
+        tapped = K > 2048 and not os.environ.get("LAB_CFG5")
+        W8b = W.to(torch.float8_e4m3fn) if w8 else None
+        w8s = torch.ones(N, device="cuda") if w8 else None
+        Wref = W8b.float() if w8 else W.float()
         aoff = lead * lda * 2
         fl = 2.0 * B * T * N * K
         ln = "LN" in name
         ln_s = W.float().sum(1).contiguous()
 
         def run(lib, with_stamps):
-            return lib.diag_gemm(C.c_void_p(A.data_ptr() + aoff), lda, 512 if K > 2048 else 0, 512 if K > 2048 else 0, C.c_void_p(W.data_ptr()), M, N, K, P, T,
+            return lib.diag_gemm(C.c_void_p(A.data_ptr() + aoff), lda, 512 if tapped else 0, 512 if tapped else 0, C.c_void_p((W8b if w8 else W).data_ptr()), M, N, K, P, T,
                                  C.c_void_p(Cb.data_ptr()), N, lead, C.c_void_p(bias.data_ptr()),
                                  C.c_void_p(Rs.data_ptr()) if res else None, act,
                                  C.c_void_p(stamps.data_ptr()) if with_stamps else None,
                                  C.c_void_p(ln_s.data_ptr()) if ln else None, st,
                                  C.c_void_p(Rlo.data_ptr()) if lo_mode else None, C.c_void_p(Clo.data_ptr()) if lo_mode else None,
-                                 C.c_void_p(Sts.data_ptr()) if Sts is not None else None)
+                                 C.c_void_p(Sts.data_ptr()) if Sts is not None else None,
+                                 C.c_void_p(w8s.data_ptr()) if w8 else None)
 
         times = {n: [] for n in libs}
         # independent reference for 64 rows spread over the run (fp32 matmul of the bf16 operands)
@@ -106,7 +114,7 @@ def main():
         Arows = torch.as_strided(A.view(-1), (B * P, K), (lda, 1), lead * lda)[ridx].float()
         if ln:
             Arows = torch.nn.functional.layer_norm(Arows, (K,))
-        ref = Arows @ W.float().T + bias
+        ref = Arows @ Wref.T + bias
         if act == 1:
             ref = torch.nn.functional.gelu(ref)
         if res:

@@ -40,6 +40,12 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define MXNCU 256
+#ifndef MX_FULL_LINE_ST
+#define MX_FULL_LINE_ST 1  // bf16 outputs: rows c and c + 8 trade halves so that a store instruction writes whole 128-byte lines
+#endif
+#ifndef MX_STAGGER_CYC
+#define MX_STAGGER_CYC 0   // s_memtime ticks (100 MHz on gfx950: 10 ns each)
+#endif
 #ifndef MX_EPI_G1_EARLY
 #define MX_EPI_G1_EARLY 1  // group 1's epilogue right behind its tile's last MFMAs (kernels without a residual): profiles/round4_mx_lab_epilogue_overlap.txt
 #endif
@@ -67,6 +73,17 @@ template <int N>
 static __device__ __forceinline__ void mx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // OUT: 0 bf16 (+ low half with RES), 1 one e4m3 plane at the fixed scale c8_inv_scale, 2 an e4m3 hi + lo pair at that scale
+template <typename T>
+__device__ __forceinline__ void mx_store_nt(T* ptr, const T& val) {     // streaming store (global_store ... nt)
+  if constexpr (sizeof(T) == 16) {
+    typedef int v4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(__builtin_bit_cast(v4, val), (v4*)ptr);
+  } else {
+    typedef int v2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(__builtin_bit_cast(v2, val), (v2*)ptr);
+  }
+}
+
 template <int ACT, int MT, bool RES, bool PAIR, int OUT>
 __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
   static_assert(OUT == 0 || !RES, "e4m3 output: no residual");
@@ -229,16 +246,27 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
       if (t >= p.P) { t -= p.P; ++b; }
       orow[u] = (m < p.M && t < p.T) ? (int)p.c_lead + b * p.c_pitch + t : -1;
     }
+#ifdef MX_ABL_FULL_LINES             // diagnostic build (wrong results, same bytes): a store / load instruction covers 8 rows x 128 B instead of 16 rows x 64 B
+#define OROW(u, h) (orow[u] + 8 * ((h) - (c >> 3)))
+#define NBH(h) (n0 + wn + 8 * g + 32 * (c >> 3))
+#else
+#define OROW(u, h) orow[u]
+#define NBH(h) (nb + 32 * (h))
+#endif
     constexpr int RING = 2;                          // (three tiles of residual halves in flight spill: a reload waits on vmcnt behind the DMA)
     bf16x8 rr[RES ? RING : 1][2], rl[RES ? RING : 1][2];
     const bf16_t* res_lo = p.res_lo ? p.res_lo : p.res;
     const float lo_scale = p.res_lo ? 1.f : 0.f;
     auto load_res = [&](int u, int slot) __attribute__((always_inline)) {
-      const long r = orow[u] >= 0 ? orow[u] : p.c_lead;
+#ifdef MX_ABL_EPI_NORES              // diagnostic build: the residual is not read (wrong results)
+      rr[slot][0] = rr[slot][1] = rl[slot][0] = rl[slot][1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      return;
+#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        rr[slot][h] = *(const bf16x8*)(p.res + r * p.ldres + nb + 32 * h);
-        rl[slot][h] = *(const bf16x8*)(res_lo + r * p.ldres + nb + 32 * h);
+        const long r = OROW(u, h) >= 0 ? OROW(u, h) : p.c_lead;
+        rr[slot][h] = *(const bf16x8*)(p.res + r * p.ldres + NBH(h));
+        rl[slot][h] = *(const bf16x8*)(res_lo + r * p.ldres + NBH(h));
       }
     };
     if (RES) {
@@ -246,10 +274,22 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
       for (int u = 0; u < RING && u < MT; ++u) load_res(u, u);
     }
     char* trash = (char*)p.trash + lane * 16;
+    // A plain bf16 output (q | k | v: 370 MB at large-v3 size, read once by the attention launch) is stored with the streaming hint: 3-9 % per
+    // launch in tools/mx_lab.py.  Not the e4m3 outputs (8-byte stores: 3-9 % slower with it) and not the residual stream (re-read next).
+#ifndef MX_ST_NT
+#define MX_ST_NT (OUT == 0 && !RES)
+#endif
+#define MX_ST(ptr, val) do { if constexpr (MX_ST_NT) mx_store_nt((ptr), (val)); else *(ptr) = (val); } while (0)
+#ifdef MX_ABL_EPI_NOSTORE            // diagnostic build: every store goes to the scratch line
+#define MX_KEEP(k) false
+#else
+#define MX_KEEP(k) (k)
+#endif
     float amax8 = 0.f;                               // e4m3 output: largest stored |x| * scale (above 448 it did not fit)
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
       __builtin_amdgcn_sched_barrier(0);
+      bf16x8 oo[2], ool[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (OUT == 2) __builtin_amdgcn_sched_barrier(0);      // (the pair output's two runs one after the other: together they spill)
@@ -281,29 +321,78 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
               lv[e >> 2] = up ? __builtin_amdgcn_cvt_pk_fp8_f32(z0, z1, lv[e >> 2], true) : __builtin_amdgcn_cvt_pk_fp8_f32(z0, z1, lv[e >> 2], false);
             }
           }
-          char* d8 = (char*)(p.c8 + (long)orow[u] * p.ldc8 + nb + 32 * h);
-          d8 = keep ? d8 : trash;
-          *(uint2*)d8 = make_uint2((unsigned)wv[0], (unsigned)wv[1]);
+          char* d8 = (char*)(p.c8 + (long)OROW(u, h) * p.ldc8 + NBH(h));
+          d8 = MX_KEEP(keep) ? d8 : trash;
+          MX_ST((uint2*)d8, make_uint2((unsigned)wv[0], (unsigned)wv[1]));
           if (OUT == 2) {
-            char* dl = (char*)(p.c8_lo + (long)orow[u] * p.ldc8 + nb + 32 * h);
-            dl = keep ? dl : trash;
-            *(uint2*)dl = make_uint2((unsigned)lv[0], (unsigned)lv[1]);
+            char* dl = (char*)(p.c8_lo + (long)OROW(u, h) * p.ldc8 + NBH(h));
+            dl = MX_KEEP(keep) ? dl : trash;
+            MX_ST((uint2*)dl, make_uint2((unsigned)lv[0], (unsigned)lv[1]));
           }
           continue;
         }
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(x[e]);
-        char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
-        dst = keep ? dst : trash;
-        *(bf16x8*)dst = o;
+        if (MX_FULL_LINE_ST) {                       // both halves first, stored below
+          oo[h] = o;
+          if (RES) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ool[h][e] = f2bf(x[e] - bf2f(o[e]));
+          }
+          continue;
+        }
+        char* dst = (char*)((bf16_t*)p.C + (long)OROW(u, h) * p.ldc + NBH(h));
+        dst = MX_KEEP(keep) ? dst : trash;
+        MX_ST((bf16x8*)dst, o);
         if (RES) {
           bf16x8 ol;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ol[e] = f2bf(x[e] - bf2f(o[e]));
-          char* dl = (char*)(p.c_lo + (long)orow[u] * p.ldc + nb + 32 * h);
-          dl = (keep && p.c_lo) ? dl : trash;
-          *(bf16x8*)dl = ol;
+          char* dl = (char*)(p.c_lo + (long)OROW(u, h) * p.ldc + NBH(h));
+          dl = MX_KEEP(keep && p.c_lo) ? dl : trash;
+          MX_ST((bf16x8*)dl, ol);
+        }
+      }
+      if (OUT == 0 && MX_FULL_LINE_ST) {
+        // A lane holds channels 8 g .. 8 g + 7 and 32 + 8 g .. of frame row c: stored as they are, an instruction writes 16 rows x 64 bytes --
+        // half lines.  Rows c and c + 8 trade one half each (DPP row_ror:8 inside the 16 lanes of a g), after which the lanes c < 8 hold the
+        // first 64 bytes of rows c and c + 8 and the lanes c >= 8 the second: every store instruction writes 8 rows x 128 bytes, whole
+        // lines (3-10 % per launch with the addresses permuted alone: profiles/round4_mx_lab_epilogue_memory.txt).
+        const bool lowhalf = c < 8;
+        auto trade = [&](const bf16x8& h0, const bf16x8& h1, bf16x8& a, bf16x8& b) __attribute__((always_inline)) {
+          const i32x4 s0 = __builtin_bit_cast(i32x4, h0), s1 = __builtin_bit_cast(i32x4, h1);
+          i32x4 ra, rb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int send = lowhalf ? s1[j] : s0[j];
+            const int recv = __builtin_amdgcn_update_dpp(0, send, 0x128, 0xf, 0xf, false);   // row_ror:8: lane c <-> lane c ^ 8
+            ra[j] = lowhalf ? s0[j] : recv;
+            rb[j] = lowhalf ? recv : s1[j];
+          }
+          a = __builtin_bit_cast(bf16x8, ra);
+          b = __builtin_bit_cast(bf16x8, rb);
+        };
+        const int po = __builtin_amdgcn_update_dpp(0, orow[u], 0x128, 0xf, 0xf, false);
+        const int rowa = lowhalf ? orow[u] : po, rowb = lowhalf ? po : orow[u];      // rows (c & 7) and (c & 7) + 8 of the block
+        const int nbx = nb + (lowhalf ? 0 : 32);
+        const bool colok = nbx < p.n_valid;
+        bf16x8 a, b;
+        trade(oo[0], oo[1], a, b);
+        char* da = (char*)((bf16_t*)p.C + (long)rowa * p.ldc + nbx);
+        char* db = (char*)((bf16_t*)p.C + (long)rowb * p.ldc + nbx);
+        da = MX_KEEP(rowa >= 0 && colok) ? da : trash;
+        db = MX_KEEP(rowb >= 0 && colok) ? db : trash;
+        MX_ST((bf16x8*)da, a);
+        MX_ST((bf16x8*)db, b);
+        if (RES) {
+          trade(ool[0], ool[1], a, b);
+          char* la = (char*)(p.c_lo + (long)rowa * p.ldc + nbx);
+          char* lb = (char*)(p.c_lo + (long)rowb * p.ldc + nbx);
+          la = MX_KEEP(rowa >= 0 && colok && p.c_lo) ? la : trash;
+          lb = MX_KEEP(rowb >= 0 && colok && p.c_lo) ? lb : trash;
+          MX_ST((bf16x8*)la, a);
+          MX_ST((bf16x8*)lb, b);
         }
       }
 #pragma unroll
@@ -324,6 +413,16 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
 #endif
 #pragma unroll
   for (int t = 0; t < R - 1; ++t) prefetch_one();
+#if MX_STAGGER_CYC > 0
+  if (RES && ntiles > 2 * G) {
+    // Residual launches of several rounds: every workgroup alternates a K loop (no HBM traffic to speak of: the operands come from L2 / MALL)
+    // and an epilogue that moves 8 bytes per output element through HBM.  Started together, all 256 run their epilogues together -- HBM
+    // idles through the K loops and is the bound through the epilogues.  A start phase per workgroup (0 .. 3 quarters of MX_STAGGER_CYC,
+    // spread over every XCD) takes them out of step.
+    const long long until = (long long)__builtin_amdgcn_s_memtime() + (long long)((blockIdx.x >> 3) & 3) * (MX_STAGGER_CYC / 4);
+    while ((long long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   wait_stage(0, false);
   __builtin_amdgcn_s_barrier();
   if (grp) __builtin_amdgcn_s_barrier();

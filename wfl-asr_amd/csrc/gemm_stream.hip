@@ -506,12 +506,19 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 
 #define SSB() __builtin_amdgcn_sched_barrier(0)
   bf16x8 fw[4], fx[MT];
+#ifndef WFL_W8_CVT_IN_C
+#define WFL_W8_CVT_IN_C 1   // W8: the e4m3 -> bf16 conversion of a step's weight fragments in the C slot (each right in front of its first MFMA) instead of the L slot
+#endif
+  uint2 fraw[W8 ? 4 : 1];
   int s = 0;                                         // global K-step counter
   int rslot = 0;                                     // its ring slot (= s % SNST)
   int ctap = 0, ccg = 0;                              // CONV: tap of the step being computed; chunks finished (buffer parity)
   auto read_frags = [&]() __attribute__((always_inline)) {
     const char* sb = smem + rslot * STB;
-    if (W8) {
+    if (W8 && WFL_W8_CVT_IN_C) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) fraw[v] = *(const uint2*)(sb + w_off[v]);     // converted behind the barrier, among the MFMAs (mma_all)
+    } else if (W8) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const uint2 raw = *(const uint2*)(sb + w_off[v]);
@@ -546,6 +553,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     for (int u = 0; u < MT; ++u) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
+        if (W8 && WFL_W8_CVT_IN_C && u == 0) {
+          const uint2 raw = fraw[v];
+          const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, true);
+          const bf16x2 c2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, false), d2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, true);
+          fw[v] = (bf16x8){a[0], a[1], b[0], b[1], c2[0], c2[1], d2[0], d2[1]};
+        }
         if (A8) {                                    // a 16-byte fragment = the k's of two fp8 MFMAs (low half, high half)
           typedef __attribute__((ext_vector_type(2))) long i64x2;
           const i64x2 a = __builtin_bit_cast(i64x2, fw[v]), b = __builtin_bit_cast(i64x2, fx[u]);
