@@ -69,6 +69,21 @@ def main():
         print(f"WavLM-large + BiLSTM + dilated (BASELINE configs[2]) | files {len(paths)} x 6-10 s at {args.rate} Hz | rows per forward {lab.batch_size}, "
               f"batches in flight {lab.n_inflight} | label_files end to end {1e3 * t_all / len(paths):.2f} ms/file = {sum(secs) / t_all:.0f} audio-s/s; "
               f"segments/file {np.mean([len(o) for o in out]):.0f}")
+        # the legs one after the other (what the loop above overlaps, or does not)
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            items = [c for chunks in ex.map(lambda q: A.load_items(q, 16000), paths) for c in chunks]
+        t_load = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        decided = lab._forward_items(items, 0, 0.5)
+        torch.cuda.synchronize()
+        t_fwd = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        segs = [lab._segments_of_item(ids, offs, "en") for ids, offs in decided]
+        t_post = time.perf_counter() - t0
+        print(f"   legs alone: load (16 threads) {1e3 * t_load:.0f} ms | forward of all {len(items)} items (sorted by length, pipelined) {1e3 * t_fwd:.0f} ms = "
+              f"{sum(secs) / t_fwd:.0f} audio-s/s | decode + median + merge {1e3 * t_post:.0f} ms | end to end above {1e3 * t_all:.0f} ms")
         return
     lab.label_files(paths[:4 * lab.batch_size], lang_id=0, confidence_threshold=0.5, verbose=False)      # warm-up
     torch.cuda.synchronize()
