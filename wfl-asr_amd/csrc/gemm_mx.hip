@@ -40,6 +40,9 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define MXNCU 256
+#ifndef MX_PRE_ISSUE
+#define MX_PRE_ISSUE 1     // at a tile boundary the next stage is issued in front of the epilogue's stores
+#endif
 #ifndef MX_FULL_LINE_ST
 #define MX_FULL_LINE_ST 1  // bf16 outputs: rows c and c + 8 trade halves so that a store instruction writes whole 128-byte lines
 #endif
@@ -434,6 +437,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
   int s = 0, rslot = 0;
   int pm0 = 0, pn0 = 0;
   bool have_prev = false;
+  bool pre_issued = false;                           // the coming C slot's stage went out in front of an epilogue already
   for (int tv = blockIdx.x; tv < ntiles; tv += G) {
     int m0, n0;
     tile_of(tv, m0, n0);
@@ -441,7 +445,16 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
       // ---- L slot (the other group issues its MFMAs meanwhile): the previous tile's epilogue, this stage's fragments, the DMA of stage s + 2
       long long tq = MXT();
-      if (kt == 0 && have_prev && !(EARLY1 && grp)) { epilogue(pm0, pn0); MXACC(st_ep, tq); tq = MXT(); }
+      if (kt == 0 && have_prev && !(EARLY1 && grp)) {
+#if MX_PRE_ISSUE
+        // The stage this step's C slot would issue goes out HERE, in front of the epilogue: a stage issued behind the stores is, in the wave's
+        // in-order vmcnt queue, a wait for the stores' acknowledgement as soon as it is awaited (one step later); this way the first such
+        // stage is the next step's, awaited two steps later.  (Its ring slot held stage s - 1, read by both groups before this interval.)
+        prefetch_one();
+        pre_issued = true;
+#endif
+        epilogue(pm0, pn0); MXACC(st_ep, tq); tq = MXT();
+      }
       const char* sb = smem + rslot * STB;
 #ifdef MX_ABL_NOLDS
       if (s == 0)
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
 #if !MX_DMA_IN_C
       prefetch_one();
 #endif
-      const bool stores = have_prev && kt < R - 2;    // the epilogue's stores are younger than the stage awaited next
+      const bool stores = have_prev && kt < R - 2 + (MX_PRE_ISSUE ? 1 : 0);   // the epilogue's stores are younger than the stage awaited next
       MXACC(st_l, tq); tq = MXT();
       if (grp) wait_stage(s + 1, stores);             // group 1 waits before the barrier ...
       __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the fragments are in registers
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
         for (int v = 0; v < 4; ++v)
           acc[u][v] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[v], fx[u], acc[u][v], 0, 0, 0, scale_w, 0, scale_x);
 #if MX_DMA_IN_C
-        if (u == 0) prefetch_one();                  // the DMA of stage s + 2 among the MFMAs: an LDS-DMA instruction issued here costs a third
+        if (u == 0) { if (pre_issued) pre_issued = false; else prefetch_one(); }   // the DMA of stage s + 2 among the MFMAs: an LDS-DMA instruction issued here costs a third
 #endif                                               //   of one issued among the L slot's ds_reads; in one clump - spread over the slot it loses 2-7 %
       }
 #else
@@ -491,7 +504,13 @@ __global__ __launch_bounds__(512) void gemm_mx_kernel(GemmArgs p) {
       // ITS epilogue at the head of the next tile's first L slot: the two epilogues overlap instead of following each other.  (Same order in
       // the wave's vmcnt queue as before: the DMA issued in this step, the stores, the DMA of the next step.)
       // (Not for the residual epilogues: those are bound by their HBM bytes, two at once gain nothing: measured -2 ... +3 %; the others +3 ... +8 %.)
-      if (EARLY1 && grp && kt == nk - 1) { epilogue(m0, n0); MXACC(st_ep, tq); tq = MXT(); }
+      if (EARLY1 && grp && kt == nk - 1) {
+#if MX_PRE_ISSUE
+        prefetch_one();                               // (the next step's stage, in front of the stores: as above)
+        pre_issued = true;
+#endif
+        epilogue(m0, n0); MXACC(st_ep, tq); tq = MXT();
+      }
       if (!grp) wait_stage(s + 1, stores);            // ... group 0 after its MFMAs
       MXACC(st_wait, tq); tq = MXT();
       if (!(grp && last_tile && kt == nk - 1)) __builtin_amdgcn_s_barrier();
