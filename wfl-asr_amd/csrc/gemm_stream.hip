@@ -40,7 +40,9 @@
                        // it the place the LDS-DMA instructions are issued from (WFL_DMA_IN_C = 1, 2: same time).  What is left is the
                        // issue cost of the 28 one-KiB LDS-DMA instructions themselves: the per-CU L2 -> LDS ceiling.
 
-#define SNCU 256
+#ifndef SNCU
+#define SNCU 256       // persistent workgroups per launch (lab: -DSNCU=128 lets two streams' launches run side by side: same step time, round 4)
+#endif
 
 typedef __attribute__((address_space(1))) const void* sgptr_t;
 typedef __attribute__((address_space(3))) void* slptr_t;
@@ -399,6 +401,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       }
     }
     char* trash = (char*)p.trash + lane * 16;
+#ifdef WFL_ABL_EPI_NOSTORE      // diagnostic build (wrong results): every output store goes to the scratch line -- what the stores cost the launch
+#define WFL_KEEP(k) false      //   (tools/ab_lib.py nostore gemm_stream.hip -DWFL_ABL_EPI_NOSTORE: cfg2 128.3 k -> 154.0 k audio-s/s, profiles/round4_cfg2_store_cost.txt)
+#else
+#define WFL_KEEP(k) (k)
+#endif
     float t1 = 0.f, t2 = 0.f;
     float amax8 = 0.f;                               // OUT8: largest stored |x| * scale (above 448 it did not fit e4m3)
 #pragma unroll
@@ -435,19 +442,19 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
           w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w0, true);
           w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], w1, true);
           char* d8 = (char*)(p.c8 + (long)orow[u] * p.ldc8 + nb + 32 * h);
-          d8 = keep ? d8 : trash;
+          d8 = WFL_KEEP(keep) ? d8 : trash;
           *(uint2*)d8 = make_uint2((unsigned)w0, (unsigned)w1);
           continue;
         }
         char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
-        dst = keep ? dst : trash;
+        dst = WFL_KEEP(keep) ? dst : trash;
         *(bf16x8*)dst = o;
         if (RES) {                                   // low half: what the bf16 rounding of the sum left behind
           bf16x8 ol;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ol[e] = f2bf(x[e] - bf2f(o[e]));
           char* dl = (char*)(p.c_lo + (long)orow[u] * p.ldc + nb + 32 * h);
-          dl = (keep && p.c_lo) ? dl : trash;
+          dl = WFL_KEEP(keep && p.c_lo) ? dl : trash;
           *(bf16x8*)dl = ol;
         }
         if (STATS) {
