@@ -565,7 +565,8 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   const int hd = a.d / a.heads;
   if (a.O8) {
     if (a.bias || hd != 64 || a.ldo8 % 4) return -4;
-    return launch_attn<64, 2, true, false, true>(a, s);
+    // (64 queries per wave here too: cfg5 with e4m3 activations 56.0 against 57.1 ms per step, whole-model A/B; WFL_ATTN_VARIANT=5: 32)
+    return attn_variant() == 5 ? launch_attn<64, 2, true, false, true>(a, s) : launch_attn<64, 4, true, false, true>(a, s);
   }
   if (a.QK_lo && a.V_lo && !a.O8) {                     // "model.precision: high": three passes over split operands
     if (a.bias && a.gate && hd == 64) return launch_attn<64, 2, true, true, false, true>(a, s);     // (WavLM-base / -large)
@@ -586,9 +587,11 @@ int wfl_launch_attention(const AttnArgs& a, hipStream_t s) {
   switch (hd) {
     case 32: return launch_attn<32, 2, true, false>(a, s);
     // head_dim 64 at cfg2 size (tools/attn_bench.py 512 8 16; WFL_ATTN_VARIANT=2 / 3: 16 / 64 queries per wave): see DESIGN.md section 4
+    // Round 4: 64 queries per wave is the default.  Per launch it equals 32 (89.1 against 89.6 us), in the whole model -- beside the other stream's
+    // launches -- it is worth 1.1 % of cfg2's step (3.62-3.64 against 3.66-3.68 ms, two runs each on one box; WFL_ATTN_VARIANT=5 selects 32 again).
     case 64: return attn_variant() == 2 ? launch_attn<64, 1, true, false>(a, s)
-                  : attn_variant() == 3 ? launch_attn<64, 4, true, false>(a, s)
-                  : attn_variant() == 4 ? launch_attn<64, 3, true, false>(a, s) : launch_attn<64, 2, true, false>(a, s);
+                  : attn_variant() == 5 ? launch_attn<64, 2, true, false>(a, s)
+                  : attn_variant() == 4 ? launch_attn<64, 3, true, false>(a, s) : launch_attn<64, 4, true, false>(a, s);
     case 128: return launch_attn<128, 2, true, false>(a, s);
     // head_dim 256, measured at cfg2 size (tools/attn_bench.py): <256, 1, no prefetch> 125 us (two workgroups per CU hide each other's
     // tile loads); <256, 2, prefetch> 166; <256, 2, no prefetch> 168; <256, 1, prefetch> 212 (one workgroup per CU each)
