@@ -99,7 +99,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #endif
   constexpr int AEXT = 224 * SBK * 2;             // CONV: extended frame tile (BMV + up to 32 taps - 1 rows), two of them
   constexpr int AOFF = SNST * STB;
-  constexpr int NSTORE = (RES ? 4 : 2) * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around; a residual
+  constexpr bool LOUT = RES || CONV;                  // epilogues that can write a low half (CONV: "model.precision: high" convs, c_lo without a residual)
+  constexpr int NSTORE = (LOUT ? 4 : 2) * MT + (STATS ? MT : 0);   // epilogue stores per wave (never branched around; a residual
                                                                   // launch always stores the hi and the lo half)
   constexpr int SROW = 4;                             // float2 slots per row of the statistics buffer (one per 256-column tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,7 +130,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
   // (CONV: the 14 row groups of the extended tile: waves 0-5 two each, 6-7 one)
   const bool two_x = CONV ? wid < 6 : (MT == 8 || wid < 4);
   const int xg0 = CONV ? (wid < 6 ? wid * 2 : 12 + (wid - 6)) : ((MT == 8 || wid < 4) ? wid * 2 : 8 + (wid - 4));
-  const int ntaps = CONV ? p.K / p.cin : 1;
+  // CONV with GemmArgs::tap_wrap ("model.precision: high"): K holds three segments [A_hi W_hi | A_lo W_hi | A_hi W_lo] of tap_wrap taps each; the
+  // channel-chunk counter then runs over 3 x (cin / SBK) chunks, chunk c of segment sg reading A at (sg == 1 ? seg_off : 0) + c * SBK and W at
+  // sg * tap_wrap * cin + tap * cin + c * SBK (the K order inside the launch: segment, chunk, tap)
+  const int ntaps = CONV ? (p.tap_wrap > 0 ? p.tap_wrap : p.K / p.cin) : 1;
+  const int nchunk = CONV ? p.cin / SBK : 1;
   const bf16_t* a_src[2];
   const bf16_t* w_src[2];
   const char* w8_src = nullptr;                     // W8: this lane's 16 source bytes of the wave's ONE weight piece (32 rows x 32 bytes)
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     else pbase += p.tap_stride;
   };
   int pcc = 0, ptap = 0, pccg = 0;                  // CONV: channel chunk / tap being issued; chunks issued so far (buffer parity)
+  long pa_off = 0, pw_off = 0;                      // CONV: element offsets of the chunk being issued into A and into a W row
   auto set_src = [&](int v) __attribute__((always_inline)) {
     int m0, n0;
     tile_of(v, m0, n0);
@@ -176,14 +182,19 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
       islot = islot + 1 == SNST ? 0 : islot + 1;
       if (ptap == 0) {                               // first tap of a channel chunk: its extended frame tile rides along
         char* ab = smem + AOFF + (pccg & 1) * AEXT;
-        sglds(a_src[0] + pcc * SBK, ab + xg0 * 1024);
-        if (two_x) sglds(a_src[1] + pcc * SBK, ab + xg0 * 1024 + 1024);
+        sglds(a_src[0] + pa_off, ab + xg0 * 1024);
+        if (two_x) sglds(a_src[1] + pa_off, ab + xg0 * 1024 + 1024);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) sglds(w_src[i] + ptap * p.cin + pcc * SBK, base + wid * 2048 + i * 1024);
+      for (int i = 0; i < 2; ++i) sglds(w_src[i] + ptap * p.cin + pw_off, base + wid * 2048 + i * 1024);
       ++issued;
       ++pkt;
-      if (++ptap == ntaps) { ptap = 0; ++pcc; ++pccg; }
+      if (++ptap == ntaps) {
+        ptap = 0; ++pcc; ++pccg;
+        if (pcc == nchunk) { pcc = 0; ++pseg; }      // (segments only with tap_wrap; a plain conv ends its tile here)
+        pa_off = (pseg == 1 ? p.seg_off : 0) + (long)pcc * SBK;
+        pw_off = (long)pseg * ntaps * p.cin + (long)pcc * SBK;
+      }
       return;
     }
     const long koff = pbase + ptap_k;
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     if (pv >= ntiles) return;
     issue_stage();
     if (pkt == nk) {
-      pkt = 0; ptap_k = 0; pbase = 0; pcc = 0; ptap = 0; ptap_i = 0; pseg = 0;
+      pkt = 0; ptap_k = 0; pbase = 0; pcc = 0; ptap = 0; ptap_i = 0; pseg = 0; pa_off = 0; pw_off = 0;
       pv += G;
       if (pv < ntiles) set_src(pv);
     }
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         char* dst = (char*)((bf16_t*)p.C + (long)orow[u] * p.ldc + nb + 32 * h);
         dst = WFL_KEEP(keep) ? dst : trash;
         *(bf16x8*)dst = o;
-        if (RES) {                                   // low half: what the bf16 rounding of the sum left behind
+        if (LOUT) {                                  // low half: what the bf16 rounding of the sum left behind
           bf16x8 ol;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ol[e] = f2bf(x[e] - bf2f(o[e]));
@@ -727,8 +738,10 @@ static bool wfl_gemm_stream_conv(const GemmArgs& a) {
   if (off) return false;
   // (at least SNST - 1 taps: a chunk's extended frame tile is issued SNST - 1 stages before its first tap and overwrites the buffer of
   //  the chunk before last, whose last tap must have been read by then)
-  return a.cin < a.K && a.K % a.cin == 0 && a.K / a.cin <= 32 && a.K / a.cin >= SNST - 1 && a.tap_stride == a.lda && a.cin % SBK == 0 &&
-         !a.res && !a.ln_s && !a.stats_out && a.tap_wrap == 0;
+  const int taps = a.tap_wrap > 0 ? a.tap_wrap : a.K / a.cin;          // (tap_wrap: three segments of that many taps, K = 3 taps cin)
+  if (a.tap_wrap > 0 && a.K != 3 * a.tap_wrap * a.cin) return false;
+  return a.cin < a.K && a.K % a.cin == 0 && taps <= 32 && taps >= SNST - 1 && a.tap_stride == a.lda && a.cin % SBK == 0 &&
+         !a.res && !a.ln_s && !a.stats_out;
 }
 
 // The launches this kernel takes (everything else stays with gemm256 / gemm).
@@ -742,7 +755,7 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   if (a.glu || a.out_f32 || a.pos || a.clip_bias) return false;
   if (a.a8 >= 2) return false;                     // gemm_mx.hip's operands
   if (a.tap_wrap > 0 && (a.ln_s || a.w8_scale || a.a8)) return false;
-  if (a.c_lo && !a.res) return false;
+  if (a.c_lo && !a.res && !wfl_gemm_stream_conv(a)) return false;      // a low half without a residual: only the conv mode's epilogue writes one
   if (a.w8_scale && (a.cin < a.K || a.K % 64)) return false;
   if (a.a8 && (!a.w8_scale || a.ln_s || a.stats_out || a.stats_in || a.K % 128 || a.lda % 16 || a.K / 64 < 8 || (a.c8 && (a.res || a.ldc8 % 8))))
     return false;
