@@ -49,7 +49,7 @@ timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 2> /dev/null | ta
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --full-head --files 768 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 512 --rate 44100 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
 WFL_GPU_INGEST=0 timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --files 256 --rate 44100 2> /dev/null | tail -1 | sed 's/^/(WFL_GPU_INGEST=0: host resampler) /' >> $OUT/e2e_label_files.txt || exit 1
-timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --wavlm --files 512 2> /dev/null | tail -1 >> $OUT/e2e_label_files.txt || exit 1
+timeout -k 10 300 python3 $ROOT/tools/e2e_bench.py --wavlm --files 512 2> /dev/null | tail -2 >> $OUT/e2e_label_files.txt || exit 1
 echo "== lstm micro"
 if [ $ROOT/wfl-asr_amd/csrc/lstm.hip -nt $ROOT/tools/micro/lstm_bench_x ] || [ ! -x $ROOT/tools/micro/lstm_bench_x ]; then
   echo "micro-benchmarks older than lstm.hip: rebuilding"; bash $ROOT/tools/micro/build.sh || exit 1
