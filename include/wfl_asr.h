@@ -182,6 +182,17 @@ int32_t wfl_op_gemm(const void* A, int64_t lda, int32_t cin, int64_t tap_stride,
                     int32_t c_pitch, const float* bias, const void* res, int64_t ldres, float alpha, int32_t act,
                     int32_t glu, int32_t out_f32, void* stream);
 
+/* The same Linear / Conv1d in the exact-label mode (`model.precision: high`; /root/reference/model.py:18-19, 26, 31-37, 131, 140 and
+ * HF modeling_whisper.py:309-354, 391-407 computed to fp32-like accuracy so that infer.py:86-96 yields the reference's tag indices):
+ * operands and results are bf16 PAIRS hi + lo (hi = bf16(x), lo = bf16(x - hi)), and
+ *   out = res_hi + res_lo + alpha * act( A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T + bias ),   C = bf16(out), C_lo = bf16(out - C).
+ * W3 is [N][3 K] bf16 with rows [W_hi | W_hi | W_lo]; A_lo has A_hi's leading dimension and tap layout (both inside one allocation);
+ * K is the layer's K (a whole number of `cin`-channel taps), K % 32 == 0, N % 256 == 0 for the MFMA kernels' fast forms. */
+int32_t wfl_op_gemm_split(const void* A_hi, const void* A_lo, int64_t lda, int32_t cin, int64_t tap_stride, const void* W3, int32_t M,
+                          int32_t N, int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, void* C_lo, int64_t ldc,
+                          int64_t c_lead, int32_t c_pitch, const float* bias, const void* res, const void* res_lo, int64_t ldres,
+                          float alpha, int32_t act, int32_t glu, void* stream);
+
 /* LayerNorm folded into the GEMM that consumes it (HF modeling_whisper.py:384-385, 401-402; model.py:18, 45):
  *   C = act( rstd_m * (A W'^T - mean_m * ln_s) + bias ),  W' = gamma o W (bf16), ln_s[n] = sum_k W'[n][k], bias = b + W beta;
  * mean / rstd are the statistics of row m of A over its K columns, computed inside the kernel.  M >= 2048, N % 256 == 0. */

@@ -181,3 +181,93 @@ def test_gemm_mx_reports_an_e4m3_output_that_does_not_fit():
         _lib.check(rc, "wfl_op_gemm_mx")
         torch.cuda.synchronize()
         assert int(status.item()) == want, (inv, int(status.item()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# wfl_op_gemm_split: the exact-label Linear / Conv1d (operands and results as bf16 pairs, three products in one launch) at the operator
+# level against a float64 product of the very pairs it is given.  The big shapes go to gemm256.hip's slice-by-slice walk (template TRI:
+# every K slice's four tiles staged once for its three products) or, for the dense multi-tap conv, to the streaming kernel's
+# tap-stationary mode.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _split(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+class _PairRows:
+    """hi and lo frame rows inside ONE allocation (the product keeps the low halves in a twin of the workspace, lo_delta away)."""
+
+    def __init__(self, B, T, Cn):
+        self.hi = G.Rows(B, T, Cn)
+        both = torch.zeros(2 * self.hi.R, Cn, dtype=torch.bfloat16, device="cuda")
+        self.hi.buf = both[:self.hi.R]
+        self.lo = G.Rows(B, T, Cn)
+        self.lo.buf = both[self.hi.R:]
+        self.both = both
+
+    def set(self, x):
+        h, l = _split(x)
+        self.hi.set(h.float())
+        self.lo.set(l.float())
+        return self
+
+    def value(self):
+        return self.hi.get().double() + self.lo.get().double()
+
+
+@pytest.mark.parametrize("mode,B,T,K,N,taps", [
+    ("plain", 3, 1500, 512, 512, 1),            # 4500 rows: TRI, 192- or 256-row tiles straddling clips
+    ("gelu", 2, 1500, 512, 2048, 1),
+    ("gelu", 16, 1500, 512, 2048, 1),           # cfg2's fc1 at full size: the 256-row tile (a 160 KiB ring)
+    ("residual", 3, 1111, 2048, 512, 1),        # a ragged last row tile
+    ("relu", 2, 1300, 768, 256, 3),             # three taps, dilation 2 (not the dense conv mode: taps two rows apart)
+    ("glu", 2, 1500, 512, 1024, 1),
+    ("residual", 1, 700, 512, 512, 1),          # one short clip: the same walk (chosen by shape, never by batch size)
+])
+def test_gemm_split_against_a_float64_product_of_its_own_pairs(mode, B, T, K, N, taps):
+    g = torch.Generator().manual_seed(3 + K + N)
+    cin = K // taps
+    dil = 2 if taps > 1 else 0
+    x = _PairRows(B, T, cin).set((torch.randn(B, T, cin, generator=g) * torch.logspace(-1, 1, cin)).cuda())
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    w_hi, w_lo = _split(w)
+    w3 = torch.cat([w_hi, w_hi, w_lo], 1).contiguous()
+    bias = torch.randn(N, generator=g).cuda()
+    n_out = N // 2 if mode == "glu" else N
+    out = _PairRows(B, T, n_out)
+    res = _PairRows(B, T, n_out).set(torch.randn(B, T, n_out, generator=g).cuda() * 4) if mode == "residual" else None
+    act = {"gelu": 1, "relu": 2}.get(mode, 0)
+    P = x.hi.P
+    lead = x.hi.lead - (taps // 2) * dil            # tap j of output frame t reads row t + (j - taps // 2) * dil (zero halos)
+    rc = G.lib().wfl_op_gemm_split(G.ptr(x.hi.buf, lead * cin), G.ptr(x.lo.buf, lead * cin), cin, cin if taps > 1 else 0, dil * cin, G.ptr(w3),
+                                   B * P, N, K, N, P, T, G.ptr(out.hi.buf), G.ptr(out.lo.buf), n_out, out.hi.lead, out.hi.P, G.ptr(bias),
+                                   G.ptr(res.hi.buf) if res else None, G.ptr(res.lo.buf) if res else None, n_out, 1.0, act, int(mode == "glu"),
+                                   G.stream())
+    _lib.check(rc, "wfl_op_gemm_split")
+    torch.cuda.synchronize()
+    xh, xl = x.hi.get().double(), x.lo.get().double()
+    if taps > 1:
+        def unfold(v):
+            v = F.pad(v, (0, 0, (taps // 2) * dil, (taps // 2) * dil))
+            return torch.cat([v[:, j * dil:j * dil + T] for j in range(taps)], 2)
+        xh, xl = unfold(xh), unfold(xl)
+    wh, wl = w_hi.double(), w_lo.double()
+    ref = xh @ wh.T + xl @ wh.T + xh @ wl.T + bias.double()           # the three products the mode computes (lo x lo is below 2^-16)
+    mag = (xh.abs() + xl.abs()) @ (wh.abs() + wl.abs()).T + bias.abs().double()
+    if mode == "glu":
+        r = ref.reshape(B, T, N // 32, 2, 16)
+        ref = (r[..., 0, :] * torch.sigmoid(r[..., 1, :])).reshape(B, T, n_out)
+        mag = mag.reshape(B, T, N // 32, 2, 16)[..., 0, :].reshape(B, T, n_out)
+    elif mode == "gelu":
+        ref = F.gelu(ref)
+    elif mode == "relu":
+        ref = F.relu(ref)
+    elif mode == "residual":
+        ref = ref + res.value()
+    got = out.value()
+    err = (got - ref).abs()
+    _note(f"gemm_split_{mode}_K{K}_N{N}_taps{taps}_B{B}", err_over_mag_max=(err / mag).max(), err_max=err.max())
+    # sixteen significant bits of the result + an fp32 accumulation over K (measured ~1e-6 of sum |a||w|)
+    assert bool((err <= 2 ** -15 * ref.abs() + 4e-6 * mag + 1e-30).all()), float((err / mag).max())
+    assert out.hi.halo_is_zero() and out.lo.halo_is_zero()

@@ -51,6 +51,7 @@ SIGNATURES = {
     "wfl_check": (_I, [_P, _P, _L, _I, _I, _P]),
     "wfl_logmel": (_I, [_P, _P, _L, _P, _I, _I, _P, _P, _L, _P]),
     "wfl_op_gemm": (_I, [_P, _L, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _I, _P, _P, _L, _F, _I, _I, _I, _P]),
+    "wfl_op_gemm_split": (_I, [_P, _P, _L, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P, _P, _L, _L, _I, _P, _P, _P, _L, _F, _I, _I, _P]),
     "wfl_op_gemm_ln": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _I, _P, _P, _F, _I, _P]),
     "wfl_op_gemm_mx": (_I, [_P, _P, _L, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _P, _P, _L, _F, _P, _P]),
     "wfl_op_rows_fp8": (_I, [_P, _L, _P, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _L, _P, _P]),

@@ -361,6 +361,8 @@ int g_wfl_gemm_kernel_id = 0;
 
 int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s);   // gemm256.hip; returns 1 when it does not take the shape
 int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s);   // gemm_stream.hip; likewise
+bool wfl_gemm256_tri_takes(const GemmArgs& a);                  // gemm256.hip: a three-segment launch its slice-by-slice walk takes
+bool wfl_gemm_stream_conv_takes(const GemmArgs& a);             // gemm_stream.hip: a launch its tap-stationary conv mode takes
 
 static int tile_pref() {
   static int pref = -1;
@@ -380,6 +382,17 @@ int wfl_launch_gemm(const GemmArgs& a, hipStream_t s) {
     return r == 1 ? -1 : r;
   }
   if (tile_pref() == 256) {
+    // "model.precision: high" launches (three segments): the slice-by-slice walk of gemm256.hip stages two thirds of the bytes of the
+    // segment-major walk; the tap-stationary conv mode (a third of them again) keeps the dense multi-tap convs.  WFL_TRI_RES=0 leaves the
+    // residual launches with the streaming kernel (A/B runs).
+    if (a.tap_wrap > 0 && wfl_gemm256_tri_takes(a) && !wfl_gemm_stream_conv_takes(a)) {
+      static int tri_res = -1;
+      if (tri_res < 0) { const char* e = getenv("WFL_TRI_RES"); tri_res = e ? atoi(e) : 1; }
+      if (!a.res || tri_res) {
+        const int r3 = wfl_launch_gemm256(a, s);
+        if (r3 != 1) return r3;
+      }
+    }
     int r = wfl_launch_gemm_stream(a, s);
     if (r != 1) return r;
     if (a.ln_s || a.w8_scale) return -1;            // only the streaming kernel folds a LayerNorm / reads e4m3 weights

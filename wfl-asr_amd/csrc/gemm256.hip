@@ -38,8 +38,16 @@ static __device__ __forceinline__ int swz2(int row) { return (-(row >> 2)) & 3; 
 #define STAMP2(k) do { } while (0)
 #endif
 
-template <int ACT, bool GLU, bool OUTF32, int MT>   // MT = 16-frame MFMA tiles per wave: 8 -> 256-row block, 6 -> 192
+// TRI ("model.precision: high", GemmArgs::tap_wrap; round 4): the launch's K holds the three segments [A_hi W_hi | A_lo W_hi | A_hi W_lo].
+//   Walked segment by segment that is 3 K / 32 stages of DMA for 3 K / 32 steps of MFMAs -- and the K loop is bound by the L2 -> LDS
+//   bytes, so the exact-label mode paid three times the default's staging.  TRI walks K SLICE by slice instead: slice j's four tiles
+//   arrive as two stages, 2j = (A_hi, W_hi) and 2j + 1 = (A_lo, W_lo), and three MFMA steps run off them,
+//       3j: A_hi W_hi (slot 2j)      3j + 1: A_lo (slot 2j + 1) W_hi (fragments kept)      3j + 2: A_hi (slot 2j) W_lo (slot 2j + 1)
+//   i.e. two stages of DMA per three steps of MFMAs (the loop turns MFMA-bound) and 3 MT + 8 fragment reads per slice instead of 3 MT + 12.
+//   Same products, same fp32 accumulators; the order of the additions differs from the segment-major walk (both are exact-label forms).
+template <int ACT, bool GLU, bool OUTF32, int MT, bool TRI = false>   // MT = 16-frame MFMA tiles per wave: 8 -> 256-row block, 6 -> 192
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+  static_assert(!TRI || !OUTF32, "three-segment launches write bf16 pairs");
   constexpr int BMV = MT * 32;              // rows of the block tile that are computed (the staged tile is always 256 rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -144,6 +152,107 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   // L(kt-1)) are drained (lgkmcnt(0)) before b(2kt); it is issued after b(2kt) (group 0) / b(2kt+1) (group 1).
   const int grp = wid >> 2;
   bf16x8 fw[4], fx[MT];
+  if constexpr (TRI) {
+    // Ring of NS3 = 5 slots of exactly one stage (frame tile of MT * 32 rows, then the weight tile), stage q in slot q % 5, three stages
+    // in flight.  Stage 2j + 3 is issued in step 3j over the slot of stage 2j - 2 (last read in step 3j - 1), stage 2j + 4 in step
+    // 3j + 1 over that of 2j - 1 (last read in step 3j - 1 too): the plain loop's "a slot is rewritten no sooner than one step after
+    // its last read".  Waits: step 3j retires stage 2j + 1, step 3j + 2 stage 2j + 2 (two younger stages stay in flight), step 3j + 1
+    // none -- a stage has four to five steps to land.
+    // What bounds it (tools/tri_stamps.py, profiles/round4_tri_stamps_*.txt): a slice takes 1.65-2.0 us; 1.2-1.5 us with the DMA removed,
+    // which is the matrix pipe itself at the clock the chip holds under this load (72 MFMAs x 2 waves per SIMD x 16 cycles = 2304 cycles:
+    // 1.44 us at 1.6 GHz, MI355X_MICROARCH.md "DVFS give-back").  Two other forms measured the same within a box's noise and were not kept:
+    // four slots with two stages in flight, and all eight waves on one register-pipelined program (two fragment sets rotating, two
+    // barriers per slice, every fragment read once: 1.74-1.83 us per slice; its 256-row form spills).
+    constexpr int XB3 = MT * 32 * BK2 * 2;            // frame tile bytes
+    constexpr int ST3 = XB3 + 256 * BK2 * 2;          // stage bytes: 28 KiB (192 rows) / 32 KiB (256 rows)
+    constexpr int NS3 = 5;
+    const int kseg = p.K / 3;
+    const int nkh = kseg / BK2;
+    const int nstage = 2 * nkh;
+    int iss = 0;                                      // stages issued so far
+    int islot = 0;                                    // slot of the next stage to issue (= iss % NS3)
+    int sk0 = 0, skin = 0;                            // slice of the next stage to issue: its k, its position inside its tap
+    long stoff = 0;                                   //   and its tap's offset (no division in the loop)
+    auto stage3 = [&]() __attribute__((always_inline)) {
+      if (iss >= nstage) return;
+      const int h = iss & 1;
+      const long koff = stoff + skin + (h ? p.seg_off : 0);
+      const int wk = sk0 + (h ? 2 * kseg : 0);
+      char* base = smem + islot * ST3;
+      glds16b(a_src[0] + koff, base + xg0 * 1024);
+      if (two_x) glds16b(a_src[1] + koff, base + xg0 * 1024 + 1024);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16b(w_src[i] + wk, base + XB3 + wid * 2048 + i * 1024);
+      ++iss;
+      islot = islot + 1 == NS3 ? 0 : islot + 1;
+      if (h) {
+        sk0 += BK2; skin += BK2;
+        if (skin == p.cin) { skin = 0; stoff += p.tap_stride; }
+      }
+    };
+    // wait until stage `need` has landed (this wave's pieces): iss - need - 1 younger stages stay in flight
+    auto wait3 = [&](int need) __attribute__((always_inline)) {
+      if (need >= nstage) return;
+      const int younger = iss - need - 1;
+      WAIT2(younger);
+    };
+    const int x3 = wm * 64 + frag_off, w3 = XB3 + wn * 64 + frag_off;
+#define LDW3(slot) _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) fw[v_] = *(const bf16x8*)(smem + (slot) * ST3 + w3 + v_ * 1024)
+#define LDX3(slot) _Pragma("unroll") for (int u_ = 0; u_ < MT; ++u_) fx[u_] = *(const bf16x8*)(smem + (slot) * ST3 + x3 + u_ * 1024)
+    stage3();
+    stage3();
+    stage3();
+    wait3(0);
+    __builtin_amdgcn_s_barrier();
+    STAMP2(1);
+    if (grp) __builtin_amdgcn_s_barrier();
+    int sh = 0;                                       // slot of stage 2j; stage 2j + 1 sits in the next one
+    for (int j = 0; j < nkh; ++j) {
+      const int sl = sh + 1 == NS3 ? 0 : sh + 1;
+      // ---- step 3j: A_hi W_hi
+      LDW3(sh);
+      LDX3(sh);
+#ifndef WFL_ABL_NOSTAGE
+      stage3();
+#endif
+      if (grp) wait3(2 * j + 1);
+      LGKM2();
+      __builtin_amdgcn_s_barrier();
+      SB2();
+      MMA2(fw, fx, 0, MT);
+      SB2();
+      if (!grp) wait3(2 * j + 1);
+      __builtin_amdgcn_s_barrier();
+      SB2();
+      // ---- step 3j + 1: A_lo W_hi (the weight fragments stay)
+      LDX3(sl);
+#ifndef WFL_ABL_NOSTAGE
+      stage3();
+#endif
+      LGKM2();
+      __builtin_amdgcn_s_barrier();
+      SB2();
+      MMA2(fw, fx, 0, MT);
+      SB2();
+      __builtin_amdgcn_s_barrier();
+      SB2();
+      // ---- step 3j + 2: A_hi W_lo
+      LDW3(sl);
+      LDX3(sh);
+      if (grp) wait3(2 * j + 2);
+      LGKM2();
+      __builtin_amdgcn_s_barrier();
+      SB2();
+      MMA2(fw, fx, 0, MT);
+      SB2();
+      if (!grp) wait3(2 * j + 2);
+      if (!(grp && j == nkh - 1)) __builtin_amdgcn_s_barrier();
+      SB2();
+      sh = sl + 1 == NS3 ? 0 : sl + 1;
+    }
+#undef LDW3
+#undef LDX3
+  } else {
 #pragma unroll
   for (int t = 0; t < NST2 - 1; ++t)
     if (t < nk) stage(t, t);
@@ -176,6 +285,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     if (!grp) WAITNEXT();
     if (!(grp && kt == nk - 1)) __builtin_amdgcn_s_barrier();
     SB2();
+  }
   }
 #undef WAITNEXT
 #undef SB2
@@ -354,23 +464,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   STAMP2(4);
 }
 
-template <int ACT, bool GLU, bool OUTF32, int MT>
+template <int ACT, bool GLU, bool OUTF32, int MT, bool TRI = false>
 static int launch256_mt(const GemmArgs& a, hipStream_t s) {
   constexpr int BMV = MT * 32;
   const int tiles = ((a.M + BMV - 1) / BMV) * (a.N / BN2);
-  auto k = gemm256_kernel<ACT, GLU, OUTF32, MT>;
+  constexpr int ring3 = 5 * (MT * 32 * BK2 * 2 + 256 * BK2 * 2);          // TRI: five one-stage slots (140 / 160 KiB)
+  constexpr int lds = TRI && ring3 > LDS2 ? ring3 : LDS2;
+  auto k = gemm256_kernel<ACT, GLU, OUTF32, MT, TRI>;
   static WflOncePerDevice attr_once;
   if (attr_once.need()) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess) return -2;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
   }
   g_wfl_gemm_kernel_id = MT == 6 ? 2 : 3;
-  hipLaunchKernelGGL(k, dim3(tiles), dim3(512), LDS2, s, a);
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // Block height: 256 or 192 rows, whichever fills the 256 CUs in fewer / fuller rounds (one block per CU).  Cost model:
 // rounds * (rows + fixed per-block overhead worth ~96 rows).
-template <int ACT, bool GLU, bool OUTF32>
+template <int ACT, bool GLU, bool OUTF32, bool TRI = false>
 static int launch256_t(const GemmArgs& a, hipStream_t s) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("WFL_GEMM_BM"); forced = e ? atoi(e) : 0; }
@@ -379,12 +491,36 @@ static int launch256_t(const GemmArgs& a, hipStream_t s) {
     return ((tiles + 255) / 256) * (long)(bm + 96);
   };
   const bool use192 = forced == 192 || (forced != 256 && cost(192) < cost(256));
-  return use192 ? launch256_mt<ACT, GLU, OUTF32, 6>(a, s) : launch256_mt<ACT, GLU, OUTF32, 8>(a, s);
+  return use192 ? launch256_mt<ACT, GLU, OUTF32, 6, TRI>(a, s) : launch256_mt<ACT, GLU, OUTF32, 8, TRI>(a, s);
+}
+
+// Three-segment launches ("model.precision: high", GemmArgs::tap_wrap) this file walks slice by slice (template TRI).  WFL_TRI=0: the
+// segment-major walk everywhere (A/B runs).
+bool wfl_gemm256_tri_takes(const GemmArgs& a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("WFL_TRI"); on = e ? atoi(e) : 1; }
+  if (!on || a.tap_wrap <= 0 || a.out_f32 || a.K % 3) return false;
+  const int kseg = a.K / 3;
+  if (kseg % BK2 || a.cin % BK2 || (long)a.tap_wrap * a.cin != kseg) return false;
+  // (no lower bound on M: the slice-by-slice walk adds its products up in another order than the segment-major one, and a clip labelled
+  //  alone has to equal the same clip inside a batch bit for bit -- the walk is chosen by shape, never by batch size)
+  if (a.N % BN2) return false;
+  if (a.glu) return a.act == WFL_ACT_NONE;
+  return a.act == WFL_ACT_NONE || a.act == WFL_ACT_GELU || a.act == WFL_ACT_RELU;
 }
 
 // Returns 1 when this kernel does not take the shape (caller falls back to the 128x128 kernel).
 int wfl_launch_gemm256(const GemmArgs& a, hipStream_t s) {
-  if (a.N % BN2 || a.K % BK2 || a.cin % BK2 || a.M < 2048) return 1;
+  if (a.N % BN2 || a.K % BK2 || a.cin % BK2) return 1;
+  if (wfl_gemm256_tri_takes(a)) {
+    if (a.glu) return launch256_t<WFL_ACT_NONE, true, false, true>(a, s);
+    switch (a.act) {
+      case WFL_ACT_NONE: return launch256_t<WFL_ACT_NONE, false, false, true>(a, s);
+      case WFL_ACT_GELU: return launch256_t<WFL_ACT_GELU, false, false, true>(a, s);
+      case WFL_ACT_RELU: return launch256_t<WFL_ACT_RELU, false, false, true>(a, s);
+    }
+  }
+  if (a.M < 2048) return 1;
   if (a.glu) return launch256_t<WFL_ACT_NONE, true, false>(a, s);
   if (a.out_f32) {
     if (a.act == WFL_ACT_NONE) return launch256_t<WFL_ACT_NONE, false, true>(a, s);

@@ -744,6 +744,7 @@ static bool wfl_gemm_stream_conv(const GemmArgs& a) {
          !a.res && !a.ln_s && !a.stats_out;
 }
 
+bool wfl_gemm_stream_conv_takes(const GemmArgs& a);
 // The launches this kernel takes (everything else stays with gemm256 / gemm).
 bool wfl_gemm_stream_takes(const GemmArgs& a) {
   static int off = -1;
@@ -771,6 +772,8 @@ bool wfl_gemm_stream_takes(const GemmArgs& a) {
   return true;
 }
 
+
+bool wfl_gemm_stream_conv_takes(const GemmArgs& a) { return wfl_gemm_stream_takes(a) && wfl_gemm_stream_conv(a); }
 
 // Returns 1 when this kernel does not take the launch (caller falls back to gemm256 / gemm).
 int wfl_launch_gemm_stream(const GemmArgs& a, hipStream_t s) {

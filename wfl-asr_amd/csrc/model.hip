@@ -2238,6 +2238,23 @@ int32_t wfl_op_gemm_ln(const void* A, int64_t lda, const void* W, int32_t M, int
   return r ? fail(r, "wfl_op_gemm_ln: shape not supported by the LayerNorm-folding kernel or launch failure (" + std::to_string(r) + ")") : 0;
 }
 
+int32_t wfl_op_gemm_split(const void* A_hi, const void* A_lo, int64_t lda, int32_t cin, int64_t tap_stride, const void* W3, int32_t M,
+                          int32_t N, int32_t K, int32_t n_valid, int32_t P, int32_t T, void* C, void* C_lo, int64_t ldc, int64_t c_lead,
+                          int32_t c_pitch, const float* bias, const void* res, const void* res_lo, int64_t ldres, float alpha,
+                          int32_t act, int32_t glu, void* stream) {
+  if (!A_hi || !A_lo || !W3 || !C || !C_lo) return fail(-1, "wfl_op_gemm_split: null argument");
+  if (K <= 0 || (cin > 0 && K % cin)) return fail(-1, "wfl_op_gemm_split: K must be a whole number of taps");
+  GemmArgs g{};
+  g.A = (const bf16_t*)A_hi; g.lda = lda; g.cin = cin > 0 ? cin : K; g.tap_stride = tap_stride;
+  g.tap_wrap = K / g.cin; g.seg_off = (long)((const bf16_t*)A_lo - (const bf16_t*)A_hi);
+  g.W = (const bf16_t*)W3; g.M = M; g.N = N; g.K = 3 * K; g.n_valid = n_valid; g.P = P; g.T = T;
+  g.C = C; g.c_lo = (bf16_t*)C_lo; g.ldc = ldc; g.c_lead = c_lead; g.c_pitch = c_pitch; g.bias = bias;
+  g.res = (const bf16_t*)res; g.res_lo = res ? (const bf16_t*)res_lo : nullptr; g.ldres = ldres; g.alpha = alpha; g.act = act; g.glu = glu;
+  g.ln_eps = 1e-5f;
+  const int r = wfl_launch_gemm(g, (hipStream_t)stream);
+  return r ? fail(r, "wfl_op_gemm_split: invalid arguments or launch failure (" + std::to_string(r) + ")") : 0;
+}
+
 int32_t wfl_op_attention(const void* QK, int64_t ldqk, int64_t lead, const void* V, int64_t ldv, void* O, int64_t ldo, int32_t B, int32_t T,
                          int32_t P, int32_t heads, int32_t d, void* stream) {
   AttnArgs a{};
