@@ -159,7 +159,8 @@ def main():
             us = np.median(times[n])
             print(f"  {n:14s} {us:7.1f} us (min {min(times[n]):7.1f}) {fl / us / 1e6:6.0f} TF | blocks {len(s):4d} | setup {np.median(ph[:, 0]):5.2f} "
                   f"K loop {np.median(ph[:, 1]):6.2f} epi stage {np.median(ph[:, 2]):5.2f} store {np.median(ph[:, 3]):5.2f} | "
-                  f"us/kstep32 {np.median(ph[:, 1]) / (K / 32):.3f} | max rel-ish err vs torch {diff:.3g}")
+                  f"us/kstep32 {np.median(ph[:, 1]) / (K / 32):.3f} | K-loop clock {np.median((s[:, 6] - s[:, 5]) / np.maximum(s[:, 2] - s[:, 1], 1) / 10.0):.2f} GHz "
+                  f"| max rel-ish err vs torch {diff:.3g}")
 
 
 if __name__ == "__main__":

@@ -84,7 +84,7 @@ def main():
                                   act, glu, 1, C.c_void_p(stamps.data_ptr()) if with_stamps else None, st)
         print(f"--- {name}  K={K} N={N}")
         for n, lib in libs.items():
-            for _ in range(3):
+            for _ in range(300):                        # (the clock settles under load: warm launches first)
                 assert run(lib, False) == 0
             torch.cuda.synchronize()
             ts = []
@@ -105,6 +105,7 @@ def main():
             us = np.median(ts)
             print(f"  {n:10s} {us:7.1f} us | blocks {len(s):4d} | setup {np.median(ph[:, 0]):5.2f} K loop {np.median(ph[:, 1]):6.2f} "
                   f"epi stage {np.median(ph[:, 2]):5.2f} store {np.median(ph[:, 3]):5.2f} | us per K slice {np.median(ph[:, 1]) / (K / 32):.3f} "
+                  f"| K-loop clock {np.median((s[:, 6] - s[:, 5]) / np.maximum(s[:, 2] - s[:, 1], 1) / 10.0):.2f} GHz "
                   f"| block start spread {(s[:, 0].max() - s[:, 0].min()) / 100.0:6.1f} us, last end {(s[:, 4].max() - s[:, 0].min()) / 100.0:6.1f} us")
 
 

@@ -33,7 +33,11 @@ static __device__ __forceinline__ void glds16b(const bf16_t* g, char* l) {
 static __device__ __forceinline__ int swz2(int row) { return (-(row >> 2)) & 3; }
 
 #ifdef WFL_GEMM_STAMPS
-#define STAMP2(k) do { if (tid == 0 && p.stamps) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// (slots 0-4: 100 MHz wall clock at the phase boundaries; slots 5 / 6: the core-clock counter at stamps 1 / 2 -- the clock the chip holds inside the
+//  K loop is their difference over the wall time between the two, MI355X_MICROARCH.md "DVFS give-back" item 6)
+#define STAMP2(k) do { if (tid == 0 && p.stamps) { p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 1) p.stamps[(long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime(); \
+    if ((k) == 2) p.stamps[(long)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define STAMP2(k) do { } while (0)
 #endif
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   float* stg = (float*)smem;
   STAMP2(2);
 #ifdef WFL_GEMM_STAMPS
-  if (tid == 0 && p.stamps) { p.stamps[(long)blockIdx.x * 8 + 6] = 0; p.stamps[(long)blockIdx.x * 8 + 7] = blockIdx.x; }
+  if (tid == 0 && p.stamps) p.stamps[(long)blockIdx.x * 8 + 7] = blockIdx.x;
 #endif
   const int cidx = tid % CP;
   const int nb = (GLU ? n0 / 2 : n0) + cidx * 8;

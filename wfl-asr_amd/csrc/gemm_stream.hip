@@ -60,7 +60,11 @@ template <int N>
 static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 #ifdef WFL_GEMM_STAMPS
-#define SSTAMP(k) do { if (tid == 0 && p.stamps) p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// (slots 0-4: 100 MHz wall clock at the phase boundaries; slots 5 / 6: the core-clock counter at stamps 1 / 2 -- the clock the chip holds inside the
+//  K loop is their difference over the wall time between the two, MI355X_MICROARCH.md "DVFS give-back" item 6)
+#define SSTAMP(k) do { if (tid == 0 && p.stamps) { p.stamps[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 1) p.stamps[(long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime(); \
+    if ((k) == 2) p.stamps[(long)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define SSTAMP(k) do { } while (0)
 #endif
