@@ -18,3 +18,6 @@ echo built tools/micro/conv0_probe tools/micro/conv0_probe_noslp tools/micro/con
 # round 4: the block-scaled fp8 MFMA's operand / scale layout and issue rate
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result tools/micro/mx_probe.hip -o tools/micro/mx_probe
 echo built tools/micro/mx_probe
+# round 4: the four-wave / 512-register form of the 192 x 256 GEMM tile (lab only)
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-result tools/micro/gemm4w.hip -o tools/micro/gemm4w
+echo built tools/micro/gemm4w
