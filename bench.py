@@ -393,7 +393,10 @@ def main():
 
         for k in range(nfl + 1):
             consumed[k].record(streams[0])
-        for i in range(args.warmup):
+        # warm-up: at least one crossing of EVERY pinned batch (the first DMA out of a freshly pinned buffer is several times slower than
+        # the later ones -- tools/h2d_lab.py, profiles/round4_h2d_lab.txt: with W = 3 of 8 buffers warmed the leg measured that first
+        # touch, 111-115 k against 127 k once every buffer had crossed; the product's loops reuse three pinned buffers for a whole folder)
+        for i in range(max(args.warmup, n_rot)):
             step_h2d(i)
         fence()
         th = time.perf_counter()

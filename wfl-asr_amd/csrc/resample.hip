@@ -80,6 +80,31 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs p) {
   }
 }
 
+// The same rate in and out (round 4: 16 kHz files take the ingest path too -- half the bytes over PCIe, no decode on the host): the
+// reference does not resample such a file (torchaudio returns the waveform as it is), so the clip is the decoded samples themselves.
+__global__ __launch_bounds__(256) void decode_kernel(ResampleArgs p) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  long target = p.n_in[b];
+  if (target > p.out_cap) target = p.out_cap;
+  const int ch = p.channels[b];
+  const long n = (long)blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (n < target) {
+    const double x = pcm_sample(p.pcm + (long)b * p.ld_in, ch, n);
+    p.tmp[(long)b * p.ld_tmp + n] = x;
+    v = fabs(x);
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v = fmax(v, __shfl_xor(v, s));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (m > 0.0) atomicMax(p.peak + b, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
 __global__ __launch_bounds__(256) void normalise_kernel(const double* __restrict__ tmp, long ld_tmp, const unsigned long long* __restrict__ peak,
                                                         const int* __restrict__ n_in, int orig, int nw, int out_cap, float* __restrict__ out,
                                                         long ld_out) {
@@ -163,11 +188,13 @@ int64_t wfl_resample_workspace_bytes(int32_t B, int32_t out_cap) {
 int32_t wfl_resample_pcm16(const int16_t* pcm, int64_t ld_in, const int32_t* n_in, const int32_t* channels, int32_t B, int32_t orig_sr,
                            int32_t new_sr, float* out, int64_t ld_out, int32_t out_cap, void* workspace, int64_t workspace_bytes,
                            void* stream) {
-  if (!pcm || !n_in || !channels || !out || !workspace || B <= 0 || orig_sr <= 0 || new_sr <= 0 || orig_sr == new_sr || out_cap <= 0 ||
+  if (!pcm || !n_in || !channels || !out || !workspace || B <= 0 || orig_sr <= 0 || new_sr <= 0 || out_cap <= 0 ||
       ld_out < out_cap || workspace_bytes < wfl_resample_workspace_bytes(B, out_cap))
     return -1;
   ResampleTable Tv;
-  if (!table_for(orig_sr, new_sr, Tv)) return -2;
+  const bool same = orig_sr == new_sr;               // decode + normalise only
+  if (same) { Tv.orig = 1; Tv.nw = 1; }
+  else if (!table_for(orig_sr, new_sr, Tv)) return -2;
   const ResampleTable* T = &Tv;
   hipStream_t s = (hipStream_t)stream;
   const long ld_tmp = ((long)out_cap + 31) / 32 * 32;
@@ -178,7 +205,8 @@ int32_t wfl_resample_pcm16(const int16_t* pcm, int64_t ld_in, const int32_t* n_i
   a.peak = (unsigned long long*)((char*)workspace + (size_t)B * ld_tmp * 8 + 256 - ((size_t)B * ld_tmp * 8) % 256);
   a.out_cap = out_cap;
   hipLaunchKernelGGL(clear_peaks_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a.peak, B);
-  hipLaunchKernelGGL(resample_kernel, dim3((out_cap + 255) / 256, B), dim3(256), 0, s, a);
+  if (same) hipLaunchKernelGGL(decode_kernel, dim3((out_cap + 255) / 256, B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(resample_kernel, dim3((out_cap + 255) / 256, B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(normalise_kernel, dim3(256, B), dim3(256), 0, s, a.tmp, ld_tmp, a.peak, n_in, T->orig, T->nw, out_cap, out, (long)ld_out);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
