@@ -74,8 +74,8 @@ def test_gpu_resample_equals_the_host_loader_bit_for_bit(tmp_path, rate):
 
 
 def test_folder_at_44k_labels_like_the_host_ingest_path(tmp_path, monkeypatch):
-    """Labeler.label_files over 44.1 kHz files (one of them 16 kHz: its own call of the ingest path since round 4; one longer than
-    30 s: the general path): the GPU ingest path gives exactly the segments of the host ingest path (WFL_GPU_INGEST=0)."""
+    """Labeler.label_files over 44.1 kHz files (one of them 16 kHz, one longer than 30 s: those keep their own paths): the
+    GPU ingest path gives exactly the segments of the host ingest path (WFL_GPU_INGEST=0)."""
     d = tmp_path
     cfg = tiny_whisper_config(enable_bilstm=False)
     cfg["model"]["encoder_arch"]["max_positions"] = 1500
@@ -105,9 +105,9 @@ def test_folder_at_44k_labels_like_the_host_ingest_path(tmp_path, monkeypatch):
     orig = lab._label_resampled
     monkeypatch.setattr(lab, "_label_resampled", lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1])
     got = lab.label_files(paths, lang_id=0, confidence_threshold=0.3, verbose=False)
-    assert calls == [7, 1]                                       # the seven short 44.1 kHz files, then the 16 kHz one; not the 40 s file
+    assert calls == [7]                                          # the seven short 44.1 kHz files, nothing else
     monkeypatch.setenv("WFL_GPU_INGEST", "0")
     ref = lab.label_files(paths, lang_id=0, confidence_threshold=0.3, verbose=False)
-    assert calls == [7, 1]
+    assert calls == [7]
     assert got == ref
     assert all(len(s) > 0 for s in got)

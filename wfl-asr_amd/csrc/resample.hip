@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs p) {
   }
 }
 
-// The same rate in and out (round 4: 16 kHz files take the ingest path too -- half the bytes over PCIe, no decode on the host): the
-// reference does not resample such a file (torchaudio returns the waveform as it is), so the clip is the decoded samples themselves.
+// The same rate in and out: the reference does not resample such a file (torchaudio returns the waveform as it is), so the clip is the
+// decoded samples themselves.  (Round 4 routed 16 kHz folders through this -- half the bytes over PCIe, no decode on the host -- and
+// measured it SLOWER end to end than the host loader's float rows on a box with a fast host: 105 k against 114 k audio-s/s,
+// profiles/round4_e2e_upload_ab.txt; Labeler keeps the host loader for files at the model's rate, the entry point keeps the case.)
 __global__ __launch_bounds__(256) void decode_kernel(ResampleArgs p) {
   __shared__ double red[4];
   const int b = blockIdx.y;

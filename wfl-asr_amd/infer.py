@@ -163,66 +163,30 @@ class Labeler:
 
         if n_batches <= 0:
             return
-        # The waveforms cross PCIe on a stream of their own, ONE BATCH AHEAD of the forward that reads them (round 4: issued from the
-        # forward's stream -- and so only once the forward two batches back had been collected -- a copy delayed its own forward while
-        # the other slot's ran alone: 3.87 against 3.73 ms per cfg2 step, tools/h2d_lab.py).  `upload` callers (the GPU ingest path) keep
-        # their copy + resample on the forward's stream.
-        ahead = upload is None and use_pipe
-        if ahead and getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(self.device)
-        staged = {}                                        # batch -> (device rows, lens, rows used), uploaded and not yet launched
-
-        def stage_in(k, lens, n):
-            host = pin[k % NI]
-            with torch.cuda.stream(self._copy_stream):
-                dev_wav = host.to(self.device, non_blocking=True)
-                ev_in = torch.cuda.Event()
-                ev_in.record(self._copy_stream)
-            copied[k % NI] = ev_in
-            staged[k] = (dev_wav, lens, n, ev_in)
-
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(fill_job, 0)
-            if ahead:
-                lens0, n0 = fut.result()
-                stage_in(0, lens0, n0)
-                fut = pool.submit(fill_job, 1) if n_batches > 1 else None
             for k in range(n_batches):
-                if ahead:
-                    dev_wav, lens, n, ev_in = staged.pop(k)
-                else:
-                    lens, n = fut.result()
-                    if k + 1 < n_batches:
-                        fut = pool.submit(fill_job, k + 1)
+                lens, n = fut.result()
+                if k + 1 < n_batches:
+                    fut = pool.submit(fill_job, k + 1)
                 slot = k % NS if use_pipe else 0
                 finish(slot)                               # the output buffer and workspace of this slot are free again
                 host = pin[k % NI]
                 stream = self._streams[slot] if use_pipe else torch.cuda.current_stream(self.device)
                 with torch.cuda.stream(stream):
-                    if ahead:
-                        stream.wait_event(ev_in)
-                        dev_wav.record_stream(stream)      # (allocated on the copy stream, read on this one)
-                    elif upload is None:
+                    if upload is None:
                         dev_wav = host.to(self.device, non_blocking=True)
-                        ev_in = torch.cuda.Event()
-                        ev_in.record(stream)
-                        copied[k % NI] = ev_in
                     else:
                         dev_wav, lens = upload(host, lens, slot, stream)
-                        ev_in = torch.cuda.Event()
-                        ev_in.record(stream)
-                        copied[k % NI] = ev_in
+                    ev_in = torch.cuda.Event()
+                    ev_in.record(stream)
+                    copied[k % NI] = ev_in
                     res = self.model.label(dev_wav, None if lang_id is None else [lang_id] * Bs, threshold=threshold, lens=lens,
                                            average_languages=lang_id is None, graph=self.use_graph, slot=slot)
                     self._pinned_out[slot].copy_(res.packed, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(stream)
                 pending[slot] = (k, n, ev)
-                del dev_wav
-                if ahead and k + 1 < n_batches:            # batch k + 1 goes up while batch k (and k - 1) run
-                    lens1, n1 = fut.result()
-                    stage_in(k + 1, lens1, n1)
-                    fut = pool.submit(fill_job, k + 2) if k + 2 < n_batches else None
             for k in range(max(0, n_batches - NS), n_batches):   # what is still in flight, oldest first
                 finish(k % NS if use_pipe else 0)
 
@@ -510,29 +474,29 @@ class Labeler:
         lang_name = self._lang_name(lang_id)
         decided_fast = {}                                 # file index -> segments of its one <= 30 s item, natively loaded
         if self.model.encoder_type == "whisper" and len(audio_paths) > 0:
-            # 16-bit PCM of at most 30 s goes to the GPU as it is -- decoded, resampled when it is not at the model's rate, and
-            # peak-normalised there (csrc/resample.hip; WFL_GPU_INGEST=0: everything on the host).  Round 4 (second half): files that
-            # ARE at the model's rate take this path too: half the bytes over PCIe, and the host only copies the file's samples
+            # only files whose header says 16 kHz are offered to the fast path (the others would be decoded there just to be turned
+            # away, and their rows forwarded empty); a header that cannot be read leaves the decision to the loader
+            cand = [fi for fi, p in enumerate(audio_paths) if A.wav_sample_rate(p) in (self.sr, None)]
+            if cand:
+                got = self._label_fast([audio_paths[fi] for fi in cand], lang_id, confidence_threshold, lang_name)
+                decided_fast = {cand[j]: seg for j, seg in got.items()}
+            # files at another rate: 16-bit PCM of at most 30 s goes to the GPU as it is and is resampled there (WFL_GPU_INGEST=0: host)
             if os.environ.get("WFL_GPU_INGEST", "1") != "0":
                 by_rate = {}
                 for fi, p in enumerate(audio_paths):
+                    if fi in decided_fast:
+                        continue
                     h = A.wav_header(p)
                     if h is None:
                         continue
                     tag, ch, sr, bits, nbytes = h
-                    if tag == 1 and bits == 16 and ch in (1, 2) and sr > 0:
+                    if tag == 1 and bits == 16 and ch in (1, 2) and sr != self.sr and sr > 0:
                         frames = nbytes // (2 * ch)
                         if 0 < frames and int(math.ceil(frames * self.sr / sr)) <= CHUNK_SAMPLES:
                             by_rate.setdefault(sr, []).append(fi)
                 for sr, fis in by_rate.items():
                     got = self._label_resampled([audio_paths[fi] for fi in fis], sr, lang_id, confidence_threshold, lang_name)
                     decided_fast.update({fis[j]: seg for j, seg in got.items()})
-            # what is left at the model's rate (other encodings: float, 24-bit ...) is decoded natively on the host, straight into
-            # the pinned batch; a header that cannot be read leaves the decision to the loader
-            cand = [fi for fi, p in enumerate(audio_paths) if fi not in decided_fast and A.wav_sample_rate(p) in (self.sr, None)]
-            if cand:
-                got = self._label_fast([audio_paths[fi] for fi in cand], lang_id, confidence_threshold, lang_name)
-                decided_fast.update({cand[j]: seg for j, seg in got.items()})
         items, owner = [], []
         chunk_lens = []
 
