@@ -281,7 +281,8 @@ int32_t wfl_host_load_wav_chunks(const char* path, int32_t target_sr, int64_t ch
  * published algorithm in float64 (/root/reference/infer.py:217-220; parity with torchaudio UNPINNED: library absent), bit-identical to
  * wfl_host_load_wav_chunks -- and whole-clip peak normalisation x / (max|x| + 1e-8) in float64 (infer.py:234-235).  Row b of `out`
  * receives min(ceil(len_b * new_sr / orig_sr), out_cap) samples followed by zeros up to out_cap; clips that come out longer than
- * out_cap (= 30 s: they would be cut into chunks) belong to wfl_host_load_wav_chunks. */
+ * out_cap (= 30 s: they would be cut into chunks) belong to wfl_host_load_wav_chunks.  orig_sr == new_sr is taken (round 4): no
+ * resampling, as torchaudio returns such a waveform as it is -- decode and normalisation only. */
 int32_t wfl_host_read_pcm16(const char* const* paths, int32_t n, int16_t* out, int64_t ld, int64_t cap_samples, int32_t* n_frames,
                             int32_t* channels, int32_t* sample_rates, int32_t* status, int32_t threads);
 int64_t wfl_resample_workspace_bytes(int32_t B, int32_t out_cap);
