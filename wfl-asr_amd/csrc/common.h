@@ -77,6 +77,7 @@ struct GemmArgs {
   float alpha;              // out = res + alpha * act(v)
   const bf16_t* pos;        // [T][ldpos] added after the activation (positional table) or null
   long ldpos;
+  const bf16_t* pos_lo;     //   the table's low half ("model.precision: high", gemm256.hip's three-segment walk only), or null
   int act;
   int glu;                  // weights row-interleaved in groups of 16 (a | gate); N_out = N / 2
   int out_f32;
@@ -286,6 +287,7 @@ int wfl_launch_gemm(const GemmArgs& a, hipStream_t s);
 extern int g_wfl_gemm_kernel_id;
 bool wfl_gemm_mx_takes(const GemmArgs& a);       // gemm_mx.hip: fp8 x fp8 on the block-scaled MFMA (GemmArgs::a8 == 2, 3)
 int wfl_launch_gemm_mx(const GemmArgs& a, hipStream_t s);
+bool wfl_gemm256_tri_takes(const GemmArgs& a);  // gemm256.hip: a three-segment launch its slice-by-slice walk takes (any number of rows)
 bool wfl_gemm_stream_takes(const GemmArgs& a);   // gemm_stream.hip: would the streaming (LayerNorm-folding) kernel take it
 int wfl_launch_attention(const AttnArgs& a, hipStream_t s);
 int wfl_launch_layernorm(const bf16_t* x, long ldx, bf16_t* y, long ldy, const float* g, const float* b, float eps,

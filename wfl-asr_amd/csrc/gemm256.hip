@@ -416,6 +416,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             const bf16x8 pp = *(const bf16x8*)(p.pos + (long)tt[pass] * p.ldpos + nb);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bf2f(pp[e]);
+            if (TRI && p.pos_lo) {                   // the table as a pair (precise.hip's order: hi, then lo)
+              const bf16x8 pl = *(const bf16x8*)(p.pos_lo + (long)tt[pass] * p.ldpos + nb);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += bf2f(pl[e]);
+            }
           }
           if (p.res) {
             if (p.res_lo) {

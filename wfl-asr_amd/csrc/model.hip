@@ -1366,11 +1366,11 @@ struct Runner {
     // One launch instead of three + the finish kernel, whenever the operand has its low half and the fused epilogues can do what the
     // layer needs: K' = 3 K with the weights packed [W_hi | W_hi | W_lo] against the taps [A_hi | A_lo | A_hi] (GemmArgs::tap_wrap; the
     // low half of A is lo_delta away), the accumulator never leaves the registers, the epilogue writes hi AND lo.  WFL_PRECISE_FUSED=0
-    // keeps the three-launch form (A/B runs); the positional-table launch (the Whisper stem's conv2) stays there for the table's low half.
+    // keeps the three-launch form (A/B runs); the positional-table launch (the Whisper stem's conv2) joined it in round 4 (below).
     static int fused_on = -1;
     if (fused_on < 0) { const char* e = getenv("WFL_PRECISE_FUSED"); fused_on = e ? atoi(e) : 1; }
-    if (fused_on && W.W3 && A_lo && !pos && lo_of(C)) {
-      GemmArgs g{};
+    GemmArgs g{};
+    if (fused_on && W.W3 && A_lo && lo_of(C)) {
       g.A = A; g.lda = lda;
       g.cin = cin > 0 ? cin : W.K; g.tap_stride = tap_stride;
       g.tap_wrap = W.K / g.cin; g.seg_off = (long)(A_lo - A);
@@ -1381,6 +1381,13 @@ struct Runner {
       g.res = res; g.ldres = ldres; g.alpha = alpha; g.res_lo = res ? lo_in(res) : nullptr;
       g.act = act; g.glu = glu ? 1 : 0; g.ln_eps = 1e-5f;
       g.c_lo = lo_of(C);
+      // the positional-table launch (the Whisper stem's conv2): one launch too when the slice-by-slice walk takes it -- its epilogue adds
+      // the table as a pair; any other kernel would drop the low half, so those shapes keep the three-launch form below
+      if (pos) { g.pos = pos; g.ldpos = ldpos; g.pos_lo = (pos == m->pos) ? m->pos_lo : nullptr; }
+    }
+    static int pos_fused = -1;                          // WFL_PRECISE_POS_FUSED=0: the table launch in the three-launch form (A/B runs)
+    if (pos_fused < 0) { const char* e = getenv("WFL_PRECISE_POS_FUSED"); pos_fused = e ? atoi(e) : 1; }
+    if (g.W && (!pos || (pos_fused && g.pos_lo && !glu && wfl_gemm256_tri_takes(g) && !wfl_gemm_stream_takes(g)))) {
       { const int ci = lo_idx(C); if (ci >= 0) lo_ok[ci] = true; }
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (m->prof_on) {
