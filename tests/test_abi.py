@@ -152,3 +152,19 @@ def test_precision_high_and_activation_formats_are_validated(libpath):
     c1["model"]["activation_dtype"] = "fp8"
     with pytest.raises(ValueError, match="weight_dtype"):
         BIOPhonemeTagger(c1, labels)
+
+
+def test_gemm_split_validates_its_arguments_without_gpu(libpath):
+    """wfl_op_gemm_split (the exact-label Linear / Conv1d at the operator level): argument errors come back as a status and a
+    message before anything is launched."""
+    from wfl_asr_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    buf = (ctypes.c_char * 64)()
+    a = ctypes.cast(buf, P)
+    # a null operand
+    rc = lib.wfl_op_gemm_split(None, a, 512, 0, 0, a, 16, 256, 512, 256, 16, 8, a, a, 256, 0, 16, None, None, None, 0, 1.0, 0, 0, None)
+    assert rc != 0 and b"wfl_op_gemm_split" in lib.wfl_last_error()
+    # K that is not a whole number of taps
+    rc = lib.wfl_op_gemm_split(a, a, 512, 96, 96, a, 16, 256, 512, 256, 16, 8, a, a, 256, 0, 16, None, None, None, 0, 1.0, 0, 0, None)
+    assert rc != 0 and b"taps" in lib.wfl_last_error()
